@@ -1,0 +1,304 @@
+/*
+ * mrcz_api.hip -- C ABI (include/mrcz_hip.h) over the gfx950 kernels: context, workspace, batch
+ * scheduling of chunks onto the device ("chunk scheduler" of the north star: replaces the one-chunk-
+ * at-a-time loop of /root/reference/src/core/workers.c:779-855 and :592-672 with batches of up to
+ * max_batch_chunks chunks per kernel sequence; no host synchronisation between batches).
+ *
+ * Single translation unit: the kernel sources are included so that one hipcc invocation produces
+ * libmrcz_hip.so.
+ */
+#include "mrcz_compress.hip"
+#include "mrcz_huffman.hip"
+#include "mrcz_inflate.hip"
+
+#include "../../include/mrcz_hip.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+using namespace mrcz;
+
+#define MAX_TIMERS 32
+
+struct mrcz_ctx {
+    int device;
+    uint32_t max_chunks;
+    hipStream_t stream;
+    char err[256];
+    /* workspace (sized for max_chunks chunks = 4*max_chunks streams) */
+    TileSum *tsum;
+    TileInfo *tinfo;
+    StreamInfo *sinfo;
+    uint32_t *blkstart;
+    uint32_t *slideq;
+    uint16_t *pairhist;
+    uint16_t *blkfreq;
+    uint32_t *blkcode;
+    uint32_t *blkhdr;
+    BlkMeta *meta;
+    BlkLay *lay;
+    uint32_t *pairbits;
+    uint32_t *pairoff;
+    uint32_t *blkbase;
+    uint64_t *result;      /* device: [0] running byte offset, [1..4] plane sums / error */
+    uint64_t *h_result;    /* pinned host mirror */
+    DecStream *dstreams;
+    uint8_t *planes;       /* decode only, allocated lazily */
+    /* timing */
+    int timing;
+    int ntimers;
+    const char *tname[MAX_TIMERS];
+    float tms[MAX_TIMERS];
+    hipEvent_t ev0, ev1;
+    /* inspection */
+    uint32_t last_streams;
+};
+
+static int fail(mrcz_ctx *c, int code, const char *what, hipError_t e)
+{
+    if (c) snprintf(c->err, sizeof(c->err), "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
+    return code;
+}
+
+#define HIPCHK(call, what)                                        \
+    do {                                                          \
+        hipError_t e_ = (call);                                   \
+        if (e_ != hipSuccess) return fail(ctx, MRCZ_EHIP, what, e_); \
+    } while (0)
+
+template <typename T> static hipError_t dalloc(T **p, size_t count) { return hipMalloc((void **)p, count * sizeof(T)); }
+
+extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chunks)
+{
+    if (!out) return MRCZ_EINVAL;
+    *out = NULL;
+    if (max_batch_chunks == 0) max_batch_chunks = 64;
+    if (max_batch_chunks > 128) max_batch_chunks = 128; /* records of one batch stay < 4 GiB */
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MRCZ_EHIP; /* no GPU: fail loudly, never fall back */
+    if (device < 0 || device >= ndev) return MRCZ_EINVAL;
+    mrcz_ctx *ctx = (mrcz_ctx *)calloc(1, sizeof(mrcz_ctx));
+    if (!ctx) return MRCZ_ENOMEM;
+    ctx->device = device;
+    ctx->max_chunks = max_batch_chunks;
+    if (hipSetDevice(device) != hipSuccess) { free(ctx); return MRCZ_EHIP; }
+    const size_t ns = 4u * (size_t)max_batch_chunks;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
+    if (e == hipSuccess) e = dalloc(&ctx->tsum, ns * TPS);
+    if (e == hipSuccess) e = dalloc(&ctx->tinfo, ns * TPS);
+    if (e == hipSuccess) e = dalloc(&ctx->sinfo, ns);
+    if (e == hipSuccess) e = dalloc(&ctx->blkstart, ns * (MAXBLK + 1));
+    if (e == hipSuccess) e = dalloc(&ctx->slideq, ns * MAXSLIDE);
+    if (e == hipSuccess) e = dalloc(&ctx->pairhist, ns * MAXPAIR * HROW);
+    if (e == hipSuccess) e = dalloc(&ctx->blkfreq, ns * MAXBLK * HROW);
+    if (e == hipSuccess) e = dalloc(&ctx->blkcode, ns * MAXBLK * HROW);
+    if (e == hipSuccess) e = dalloc(&ctx->blkhdr, ns * MAXBLK * HDRWORDS);
+    if (e == hipSuccess) e = dalloc(&ctx->meta, ns * MAXBLK);
+    if (e == hipSuccess) e = dalloc(&ctx->lay, ns * MAXBLK);
+    if (e == hipSuccess) e = dalloc(&ctx->pairbits, ns * MAXPAIR);
+    if (e == hipSuccess) e = dalloc(&ctx->pairoff, ns * MAXPAIR);
+    if (e == hipSuccess) e = dalloc(&ctx->blkbase, ns + 1);
+    if (e == hipSuccess) e = dalloc(&ctx->result, 8);
+    if (e == hipSuccess) e = dalloc(&ctx->dstreams, ns);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e != hipSuccess) {
+        mrcz_destroy(ctx);
+        return e == hipSuccess ? MRCZ_ENOMEM : MRCZ_ENOMEM;
+    }
+    *out = ctx;
+    return MRCZ_OK;
+}
+
+extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->tsum); (void)hipFree(ctx->tinfo); (void)hipFree(ctx->sinfo); (void)hipFree(ctx->blkstart);
+    (void)hipFree(ctx->slideq); (void)hipFree(ctx->pairhist); (void)hipFree(ctx->blkfreq); (void)hipFree(ctx->blkcode);
+    (void)hipFree(ctx->blkhdr); (void)hipFree(ctx->meta); (void)hipFree(ctx->lay); (void)hipFree(ctx->pairbits);
+    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams);
+    (void)hipFree(ctx->planes);
+    if (ctx->h_result) (void)hipHostFree(ctx->h_result);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    free(ctx);
+}
+
+extern "C" const char *mrcz_last_error(const mrcz_ctx_t *ctx) { return ctx ? ctx->err : "no context"; }
+extern "C" void *mrcz_stream(mrcz_ctx_t *ctx) { return ctx ? (void *)ctx->stream : NULL; }
+extern "C" int mrcz_set_timing(mrcz_ctx_t *ctx, int on)
+{
+    if (!ctx) return MRCZ_EINVAL;
+    ctx->timing = on ? 1 : 0;
+    return MRCZ_OK;
+}
+
+extern "C" uint64_t mrcz_records_bound(uint64_t nfloats)
+{
+    const uint64_t nchunks = (nfloats + CHK - 1) / CHK;
+    return nchunks * 16u + nfloats * 4u + 64u;
+}
+
+/* run one kernel launch, optionally timed with HIP events on the context's stream */
+#define LAUNCH(name, kernel, grid, block, ...)                                              \
+    do {                                                                                    \
+        if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);                       \
+        hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, __VA_ARGS__);               \
+        if (ctx->timing) {                                                                  \
+            (void)hipEventRecord(ctx->ev1, ctx->stream);                                    \
+            (void)hipEventSynchronize(ctx->ev1);                                            \
+            float ms_ = 0.f;                                                                \
+            (void)hipEventElapsedTime(&ms_, ctx->ev0, ctx->ev1);                            \
+            timer_add(ctx, name, ms_);                                                      \
+        }                                                                                   \
+        HIPCHK(hipGetLastError(), name);                                                    \
+    } while (0)
+
+static void timer_add(mrcz_ctx *ctx, const char *name, float ms)
+{
+    for (int i = 0; i < ctx->ntimers; i++)
+        if (ctx->tname[i] == name || strcmp(ctx->tname[i], name) == 0) { ctx->tms[i] += ms; return; }
+    if (ctx->ntimers < MAX_TIMERS) {
+        ctx->tname[ctx->ntimers] = name;
+        ctx->tms[ctx->ntimers] = ms;
+        ctx->ntimers++;
+    }
+}
+
+extern "C" int mrcz_last_timings(const mrcz_ctx_t *ctx, const char **names, float *ms, int max)
+{
+    if (!ctx) return 0;
+    int n = ctx->ntimers < max ? ctx->ntimers : max;
+    for (int i = 0; i < n; i++) { names[i] = ctx->tname[i]; ms[i] = ctx->tms[i]; }
+    return n;
+}
+
+static uint32_t mask_of(int bits) { return bits >= 32 ? 0u : (0xFFFFFFFFu << bits); } /* workers.c:29-37 */
+
+extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk, int bits,
+                                    void *d_out, uint64_t out_cap, uint64_t *out_len, uint64_t plane_bytes[4])
+{
+    if (!ctx || !d_in || !d_out || !out_len) return MRCZ_EINVAL;
+    if (bits < 0 || bits > 32) return fail(ctx, MRCZ_EINVAL, "bits outside 0..32 (reference table has 33 entries, workers.c:29-37)", hipSuccess);
+    if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 3u)) return fail(ctx, MRCZ_EINVAL, "d_in must be 16-byte and d_out 4-byte aligned", hipSuccess);
+    *out_len = 0;
+    ctx->ntimers = 0;
+    if (nfloats == 0) return MRCZ_OK;
+    const uint64_t bound = mrcz_records_bound(nfloats);
+    if (out_cap < bound) return fail(ctx, MRCZ_ECAP, "output capacity below mrcz_records_bound()", hipSuccess);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const uint32_t mask = mask_of(bits);
+    const uint64_t nchunks = (nfloats + CHK - 1) / CHK;
+    const uint32_t *in = (const uint32_t *)d_in;
+    uint8_t *out = (uint8_t *)d_out;
+    HIPCHK(hipMemsetAsync(ctx->result, 0, 8 * sizeof(uint64_t), ctx->stream), "memset result");
+    HIPCHK(hipMemsetAsync(out, 0, (size_t)((bound + 3u) & ~3ull), ctx->stream), "memset output");
+
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += ctx->max_chunks) {
+        const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
+        const uint32_t ns = 4u * nb;
+        const uint32_t *bin = in + c0 * CHK;
+        const uint64_t bfl = (nfloats - c0 * CHK) < (uint64_t)nb * CHK ? (nfloats - c0 * CHK) : (uint64_t)nb * CHK;
+        const uint32_t fstart = (first_chunk + c0 == 0) ? 1u : 0u;
+        ctx->last_streams = ns;
+        LAUNCH("k_tile_summary", k_tile_summary, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, ctx->tsum);
+        LAUNCH("k_stream_scan", k_stream_scan, dim3(ns), dim3(256), ctx->tsum, bfl, ctx->tinfo, ctx->sinfo, ctx->blkstart);
+        LAUNCH("k_histogram", k_histogram, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, ctx->tinfo, ctx->pairhist,
+               ctx->blkstart, ctx->slideq);
+        LAUNCH("k_block_reduce", k_block_reduce, dim3(MAXBLK, ns), dim3(64), ctx->tinfo, ctx->sinfo, ctx->pairhist, ctx->blkfreq);
+        LAUNCH("k_block_index", k_block_index, dim3(1), dim3(256), ctx->sinfo, ns, ctx->blkbase);
+        LAUNCH("k_huffman", k_huffman, dim3((ns * MAXBLK + HT - 1) / HT), dim3(HT), ctx->sinfo, ns, ctx->blkbase, ctx->blkfreq,
+               ctx->blkcode, ctx->blkhdr, ctx->meta);
+        LAUNCH("k_stream_layout", k_stream_layout, dim3(ns), dim3(64), ctx->sinfo, ctx->meta, ctx->blkstart, ctx->slideq, ctx->lay);
+        LAUNCH("k_pair_bits", k_pair_bits, dim3(SPS, ns), dim3(64), ctx->sinfo, ctx->lay, ctx->pairhist, ctx->blkcode, ctx->tinfo,
+               ctx->pairbits);
+        LAUNCH("k_pair_offsets", k_pair_offsets, dim3(ns), dim3(64), ctx->sinfo, ctx->lay, ctx->tinfo, ctx->pairbits, ctx->pairoff);
+        LAUNCH("k_container", k_container, dim3(1), dim3(256), ctx->sinfo, nb, out, ctx->result);
+        LAUNCH("k_emit", k_emit, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, ctx->tinfo, ctx->sinfo, ctx->lay, ctx->blkstart,
+               ctx->blkcode, ctx->pairoff, out);
+        LAUNCH("k_emit_headers", k_emit_headers, dim3(MAXBLK + 1, ns), dim3(64), ctx->sinfo, ctx->lay, ctx->meta, ctx->blkhdr,
+               ctx->blkstart, out);
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_result, ctx->result, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (compress)");
+    *out_len = ctx->h_result[0];
+    if (plane_bytes)
+        for (int j = 0; j < 4; j++) plane_bytes[j] = ctx->h_result[1 + j];
+    return MRCZ_OK;
+}
+
+extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
+                                      void *d_out, uint64_t *consumed)
+{
+    if (!ctx || !d_out) return MRCZ_EINVAL;
+    if (consumed) *consumed = 0;
+    ctx->ntimers = 0;
+    if (nfloats == 0) return MRCZ_OK;
+    if (!d_records) return MRCZ_EINVAL;
+    if (chk == 0 || chk > CHK) return fail(ctx, MRCZ_EFORMAT, "chunk size in header exceeds CHUNK_SIZE (constant.h:25)", hipSuccess);
+    if ((uintptr_t)d_out & 15u) return fail(ctx, MRCZ_EINVAL, "d_out must be 16-byte aligned", hipSuccess);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    if (!ctx->planes) {
+        hipError_t e = hipMalloc((void **)&ctx->planes, (size_t)4 * ctx->max_chunks * CHK);
+        if (e != hipSuccess) return fail(ctx, MRCZ_ENOMEM, "plane workspace", e);
+    }
+    const uint8_t *rec = (const uint8_t *)d_records;
+    uint32_t *out = (uint32_t *)d_out;
+    const uint64_t nchunks = (nfloats + chk - 1) / chk;
+    HIPCHK(hipMemsetAsync(ctx->result, 0, 8 * sizeof(uint64_t), ctx->stream), "memset result");
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += ctx->max_chunks) {
+        const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
+        const uint64_t bfl = (nfloats - c0 * chk) < (uint64_t)nb * chk ? (nfloats - c0 * chk) : (uint64_t)nb * chk;
+        LAUNCH("k_parse_records", k_parse_records, dim3(1), dim3(64), rec, len, bfl, chk, ctx->dstreams, ctx->result);
+        LAUNCH("k_inflate", k_inflate, dim3(4 * nb), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result);
+        LAUNCH("k_merge_planes", k_merge_planes, dim3(1024, nb), dim3(256), ctx->planes, bfl, chk, out + c0 * chk);
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_result, ctx->result, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (uncompress)");
+    if (consumed) *consumed = ctx->h_result[0];
+    if (ctx->h_result[1]) return fail(ctx, MRCZ_EFORMAT, "malformed chunk records or deflate stream", hipSuccess);
+    return MRCZ_OK;
+}
+
+extern "C" int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, uint64_t first_word_index, int bits)
+{
+    if (!ctx || !d_words) return MRCZ_EINVAL;
+    if (bits < 0 || bits > 32) return fail(ctx, MRCZ_EINVAL, "bits outside 0..32", hipSuccess);
+    if (nwords == 0) return MRCZ_OK;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->ntimers = 0;
+    LAUNCH("k_erase_bits", k_erase_bits, dim3(2048), dim3(256), (uint32_t *)d_words, nwords, first_word_index, mask_of(bits));
+    HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (erase)");
+    return MRCZ_OK;
+}
+
+extern "C" int mrcz_debug_blocks(mrcz_ctx_t *ctx, uint32_t stream, mrcz_block_info_t *blocks, uint32_t max_blocks)
+{
+    if (!ctx || stream >= ctx->last_streams) return MRCZ_EINVAL;
+    StreamInfo si;
+    if (hipMemcpy(&si, ctx->sinfo + stream, sizeof(si), hipMemcpyDeviceToHost) != hipSuccess) return MRCZ_EHIP;
+    uint32_t nb = si.nblk;
+    if (nb > (uint32_t)MAXBLK) return MRCZ_EFORMAT;
+    BlkLay *lay = (BlkLay *)malloc(sizeof(BlkLay) * (nb + 1));
+    BlkMeta *meta = (BlkMeta *)malloc(sizeof(BlkMeta) * (nb + 1));
+    uint32_t *bs = (uint32_t *)malloc(sizeof(uint32_t) * (nb + 2));
+    (void)hipMemcpy(lay, ctx->lay + (size_t)stream * MAXBLK, sizeof(BlkLay) * nb, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(meta, ctx->meta + (size_t)stream * MAXBLK, sizeof(BlkMeta) * nb, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(bs, ctx->blkstart + (size_t)stream * (MAXBLK + 1), sizeof(uint32_t) * (nb + 1), hipMemcpyDeviceToHost);
+    for (uint32_t b = 0; b < nb && b < max_blocks; b++) {
+        blocks[b].start = bs[b];
+        blocks[b].end = bs[b + 1];
+        blocks[b].btype = lay[b].btype;
+        blocks[b].opt_len = meta[b].opt_len;
+        blocks[b].static_len = meta[b].static_len;
+        blocks[b].bitpos = lay[b].bitpos;
+    }
+    free(lay); free(meta); free(bs);
+    return (int)nb;
+}

@@ -1,0 +1,900 @@
+/*
+ * mrcz_compress.hip -- gfx950 kernels of the compressor.
+ *
+ * Replaces, for a batch of chunks resident in HBM, the reference's per-chunk body of run_compress
+ * (/root/reference/src/core/workers.c:779-855): apply_mask + split_float_to_byte_stream
+ * (workers.c:82-101,180-203) and 4 x mzlib_def (zip.c:164-196), i.e. zlib 1.2.8
+ * deflate(level 6, raw, memLevel 9, Z_RLE, Z_FULL_FLUSH) -- emitted bit-exactly.
+ *
+ * Pass structure (all passes read the float input directly; planes are never materialised in HBM):
+ *   k_tile_summary   4N B read : per (stream, tile) run summary + interior symbol count
+ *   k_stream_scan    small     : run extensions across tiles, symbol prefix, block count
+ *   k_histogram      4N B read : per (segment, block) "pair" histograms, block start positions,
+ *                                window-slide positions (App. B.4)
+ *   k_block_reduce   small     : block histograms
+ *   k_huffman        small     : zlib-exact Huffman construction, dynamic headers      (mrcz_huffman.hip)
+ *   k_stream_layout  small     : stored/static/dynamic choice, block bit offsets, RAW test
+ *   k_pair_bits/_off small     : bit offset of every pair
+ *   k_container      small     : payload offsets + 16-byte chunk headers
+ *   k_emit           4N B read, Z B written : Huffman/stored/raw bit packing
+ *   k_emit_headers   small     : block headers, END_BLOCK codes, sync markers
+ * No MFMA anywhere: the path is byte/bit manipulation bound by HBM and LDS.
+ */
+#include "mrcz_tile.h"
+
+namespace mrcz {
+
+/* ======================================================================================
+ * pass 1: tile summaries
+ * ==================================================================================== */
+__global__ __launch_bounds__(256) void k_tile_summary(const uint32_t *__restrict__ in, uint64_t nfloats,
+                                                      uint32_t mask, uint32_t first_chunk_is_file_start,
+                                                      TileSum *__restrict__ tsum)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PLANE_LDS];
+    const uint32_t g = blockIdx.x, c = blockIdx.y;
+    const uint64_t cbase = (uint64_t)c * CHK;
+    const uint32_t n = (uint32_t)((nfloats - cbase) < CHK ? (nfloats - cbase) : CHK);
+    if ((uint64_t)g * SEG >= n) return;
+    const uint32_t *cin = in + cbase;
+    const uint32_t unmasked = (c == 0 && first_chunk_is_file_start) ? 256u : 0u;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const uint32_t s = 4u * c + (uint32_t)w;
+
+    for (int ti = 0; ti < TILES_PER_SEG; ti++) {
+        const uint32_t t0 = g * SEG + ti * TILE;
+        if (t0 >= n) break;
+        const int len = (int)((n - t0) < (uint32_t)TILE ? (n - t0) : (uint32_t)TILE);
+        stage_tile(cin, t0, (uint32_t)len, mask, unmasked, lds);
+        __syncthreads();
+        const uint8_t *plane = lds + w * PLANE_LDS;
+        uint32_t x[16];
+        lane_row(plane, lane, x);
+        const LaneTile lt = analyse_lane(x, lane, len, 0u, 0u);
+        /* head: first run start at tile position >= 1 */
+        const uint64_t Eh = (lane == 0) ? (lt.E & ~1ull) : lt.E;
+        int head = wave_min_i(Eh ? lt.a + ctz64(Eh) : 0x40000000);
+        if (head > len) head = len;
+        const uint64_t Et = Eh & lt.V;
+        const int tailstart = wave_max_i(Et ? lt.a + 63 - clz64(Et) : -1); /* -1: uniform tile */
+        const int tail = tailstart < 0 ? len : len - tailstart;
+        const LaneCls cls = classify_lane(lt.E, lt.a, lt.prevS, lt.nextS);
+        /* body = positions in [head, tailstart) */
+        uint64_t bm = 0;
+        if (tailstart > head) {
+            const int lo = head - lt.a, hi = tailstart - lt.a; /* lane-relative */
+            const uint64_t mlo = lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+            const uint64_t mhi = hi >= 64 ? ~0ull : (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
+            bm = mlo & mhi;
+        }
+        const uint32_t body = wave_sum_u((uint32_t)popc64(cls.S & lt.V & bm));
+        if (lane == 0) {
+            TileSum ts;
+            ts.head = (uint16_t)head;
+            ts.tail = (uint16_t)tail;
+            ts.len = (uint16_t)len;
+            ts.fb = plane[0];
+            ts.lb = plane[((len - 1) >> 6) * ROWPAD + ((len - 1) & 63)];
+            ts.body = body;
+            ts.pad = 0;
+            tsum[(size_t)s * TPS + (t0 / TILE)] = ts;
+        }
+        __syncthreads();
+    }
+}
+
+/* ======================================================================================
+ * pass 2 (small): per-stream scans over tile summaries
+ * ==================================================================================== */
+struct SegPair {
+    uint32_t sum;
+    uint32_t brk;
+};
+__device__ __forceinline__ SegPair seg_combine(SegPair a, SegPair b)
+{
+    SegPair r;
+    r.sum = b.brk ? b.sum : a.sum + b.sum;
+    r.brk = a.brk | b.brk;
+    return r;
+}
+/* exclusive scan of per-thread aggregates over a 256-thread block (4 waves) */
+__device__ __forceinline__ SegPair block_excl_scan(SegPair v, SegPair *wsum /* [4] shared */)
+{
+    const int l = lane_id(), w = threadIdx.x >> 6;
+    SegPair x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        SegPair y;
+        y.sum = __shfl_up(x.sum, d);
+        y.brk = __shfl_up(x.brk, d);
+        if (l >= d) x = seg_combine(y, x);
+    }
+    if (l == 63) wsum[w] = x;
+    SegPair e;
+    e.sum = __shfl_up(x.sum, 1);
+    e.brk = __shfl_up(x.brk, 1);
+    if (l == 0) { e.sum = 0; e.brk = 0; }
+    __syncthreads();
+    SegPair pre;
+    pre.sum = 0;
+    pre.brk = 0;
+    for (int i = 0; i < w; i++) pre = seg_combine(pre, wsum[i]);
+    __syncthreads();
+    return seg_combine(pre, e);
+}
+
+constexpr int TPT = TPS / 256; /* tiles per thread = 6 */
+
+__global__ __launch_bounds__(256) void k_stream_scan(const TileSum *__restrict__ tsum, uint64_t nfloats,
+                                                     TileInfo *__restrict__ tinfo, StreamInfo *__restrict__ sinfo,
+                                                     uint32_t *__restrict__ blkstart)
+{
+    __shared__ uint16_t s_head[TPS], s_tail[TPS], s_len[TPS];
+    __shared__ uint8_t s_fb[TPS], s_lb[TPS];
+    __shared__ uint32_t s_c[TPS];   /* backward run length ending at the tile's end */
+    __shared__ uint32_t s_h[TPS];   /* forward run length starting at the tile's start */
+    __shared__ SegPair wsum[4];
+    const uint32_t s = blockIdx.x, c = s >> 2;
+    const uint64_t cbase = (uint64_t)c * CHK;
+    const uint32_t n = (uint32_t)((nfloats - cbase) < CHK ? (nfloats - cbase) : CHK);
+    const int nt = (int)((n + TILE - 1) / TILE);
+    const TileSum *ts = tsum + (size_t)s * TPS;
+    for (int t = threadIdx.x; t < nt; t += 256) {
+        const TileSum v = ts[t];
+        s_head[t] = v.head; s_tail[t] = v.tail; s_len[t] = v.len; s_fb[t] = v.fb; s_lb[t] = v.lb;
+    }
+    __syncthreads();
+    const int tb = threadIdx.x * TPT;
+    /* ---- backward extension: c_t = tail_t, or len_t + c_{t-1} when the tile is uniform and continues t-1 ---- */
+    {
+        SegPair agg;
+        agg.sum = 0;
+        agg.brk = 0;
+        SegPair loc[TPT];
+        for (int j = 0; j < TPT; j++) {
+            const int t = tb + j;
+            SegPair e;
+            e.sum = 0;
+            e.brk = 0;
+            if (t < nt) {
+                const bool uni = s_head[t] == s_len[t];
+                const bool cont = uni && t > 0 && s_lb[t - 1] == s_fb[t];
+                e.sum = s_tail[t];
+                e.brk = cont ? 0u : 1u;
+            }
+            agg = seg_combine(agg, e);
+            loc[j] = agg;
+        }
+        const SegPair pre = block_excl_scan(agg, wsum);
+        for (int j = 0; j < TPT; j++) {
+            const int t = tb + j;
+            if (t < nt) s_c[t] = seg_combine(pre, loc[j]).sum;
+        }
+    }
+    /* ---- forward extension (scan over reversed tile order) ---- */
+    {
+        SegPair agg;
+        agg.sum = 0;
+        agg.brk = 0;
+        SegPair loc[TPT];
+        for (int j = 0; j < TPT; j++) {
+            const int t = nt - 1 - (tb + j);
+            SegPair e;
+            e.sum = 0;
+            e.brk = 0;
+            if (t >= 0) {
+                const bool uni = s_head[t] == s_len[t];
+                const bool cont = uni && t + 1 < nt && s_fb[t + 1] == s_lb[t];
+                e.sum = s_head[t];
+                e.brk = cont ? 0u : 1u;
+            }
+            agg = seg_combine(agg, e);
+            loc[j] = agg;
+        }
+        const SegPair pre = block_excl_scan(agg, wsum);
+        for (int j = 0; j < TPT; j++) {
+            const int t = nt - 1 - (tb + j);
+            if (t >= 0) s_h[t] = seg_combine(pre, loc[j]).sum;
+        }
+    }
+    __syncthreads();
+    /* ---- symbol counts + prefix ---- */
+    uint32_t Bv[TPT], Fv[TPT], cntv[TPT];
+    SegPair agg;
+    agg.sum = 0;
+    agg.brk = 0;
+    for (int j = 0; j < TPT; j++) {
+        const int t = tb + j;
+        Bv[j] = Fv[j] = cntv[j] = 0;
+        if (t < nt) {
+            const uint32_t len = s_len[t], head = s_head[t], tail = s_tail[t];
+            const uint32_t B = (t > 0 && s_lb[t - 1] == s_fb[t]) ? s_c[t - 1] : 0u;
+            const uint32_t F = (t + 1 < nt && s_fb[t + 1] == s_lb[t]) ? s_h[t + 1] : 0u;
+            uint32_t cnt;
+            if (head == len) { /* uniform: one run through the whole tile */
+                const uint32_t L = B + len + F;
+                cnt = run_syms_before(L, B + len) - run_syms_before(L, B);
+            } else {
+                const uint32_t Lh = B + head;
+                const uint32_t Lt = tail + F;
+                cnt = ts[t].body + (run_syms_before(Lh, Lh) - run_syms_before(Lh, B)) + run_syms_before(Lt, tail);
+            }
+            Bv[j] = B; Fv[j] = F; cntv[j] = cnt;
+        }
+        agg.sum += cntv[j];
+    }
+    const SegPair pre = block_excl_scan(agg, wsum);
+    uint32_t P = pre.sum;
+    for (int j = 0; j < TPT; j++) {
+        const int t = tb + j;
+        if (t < nt) {
+            TileInfo ti;
+            ti.B = Bv[j]; ti.F = Fv[j]; ti.P = P; ti.cnt = cntv[j];
+            tinfo[(size_t)s * TPS + t] = ti;
+            P += cntv[j];
+        }
+    }
+    /* total: the thread that owns the last tile knows it */
+    const int tl = nt - 1;
+    if (tl >= tb && tl < tb + TPT) {
+        StreamInfo si;
+        si.n = n;
+        si.ntiles = (uint32_t)nt;
+        si.nseg = (n + SEG - 1) / SEG;
+        si.nsym = P;
+        si.nblk = (P + BLK_SYMS - 1) / BLK_SYMS;
+        si.zbits = 0; si.zlen = 0; si.raw = 0; si.payoff = 0; si.paylen = 0; si.pad = 0;
+        sinfo[s] = si;
+        blkstart[(size_t)s * (MAXBLK + 1) + si.nblk] = n;
+    }
+}
+
+/* ======================================================================================
+ * pass 3: pair histograms, block starts, window-slide positions
+ * ==================================================================================== */
+
+/* window-slide thresholds of a stream of n bytes: slide k (1-based) happens at
+ * the first token boundary q >= T_k.  Returns the number of slides J and, for index k in [1, J],
+ * the threshold via slide_threshold(). */
+__host__ __device__ __forceinline__ uint32_t slide_count(uint32_t n)
+{
+    /* steady slides: T_k = 32768 (k+1) - 258 while 32768 (k+1) <= n */
+    const uint32_t js = n >= 65536u ? n / 32768u - 1u : 0u;
+    const uint32_t base = 32768u * js;
+    const uint32_t rem = n - base; /* bytes the window holds once input is exhausted */
+    /* one more slide in the exhausted state iff 65274 <= rem < 65536 */
+    return js + ((rem >= 65274u && rem < 65536u) ? 1u : 0u);
+}
+__host__ __device__ __forceinline__ uint32_t slide_threshold(uint32_t n, uint32_t k /* 1-based */)
+{
+    const uint32_t js = n >= 65536u ? n / 32768u - 1u : 0u;
+    if (k <= js) return 32768u * (k + 1u) - 258u;
+    const uint32_t base = 32768u * js;
+    const uint32_t a = base + 65274u, b = n - 258u;
+    return a > b ? a : b;
+}
+
+/* first token boundary at or after tile-relative position p (p is inside this lane's 64 positions
+ * and valid); cls = this lane's classification */
+__device__ __forceinline__ int token_boundary_at(const LaneTile &lt, const LaneCls &cls, int p)
+{
+    const int i = p - lt.a;
+    if ((cls.S >> i) & 1ull) return p;
+    /* covered: p lies in a run started at s with d >= 2; chunk start = p - m, len = min(258, f + m) */
+    const uint64_t below = (i == 63) ? lt.E : (lt.E & ((1ull << (i + 1)) - 1ull));
+    const int srun = below ? lt.a + 63 - clz64(below) : lt.prevS;
+    const uint64_t above = (i == 63) ? 0ull : (lt.E >> (i + 1));
+    const int trun = above ? p + 1 + ctz64(above) : lt.nextS;
+    const int d = p - srun, f = trun - p;
+    const int m = (d - 1) % 258;
+    int l = f + m;
+    if (l > 258) l = 258;
+    return p - m + l;
+}
+
+__global__ __launch_bounds__(256) void k_histogram(const uint32_t *__restrict__ in, uint64_t nfloats, uint32_t mask,
+                                                   uint32_t first_chunk_is_file_start,
+                                                   const TileInfo *__restrict__ tinfo, uint16_t *__restrict__ pairhist,
+                                                   uint32_t *__restrict__ blkstart, uint32_t *__restrict__ slideq)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PLANE_LDS];
+    __shared__ uint32_t rows[4][2][HROW];
+    const uint32_t g = blockIdx.x, c = blockIdx.y;
+    const uint64_t cbase = (uint64_t)c * CHK;
+    const uint32_t n = (uint32_t)((nfloats - cbase) < CHK ? (nfloats - cbase) : CHK);
+    if ((uint64_t)g * SEG >= n) return;
+    const uint32_t *cin = in + cbase;
+    const uint32_t unmasked = (c == 0 && first_chunk_is_file_start) ? 256u : 0u;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const uint32_t s = 4u * c + (uint32_t)w;
+    uint32_t *rowA = rows[w][0], *rowB = rows[w][1];
+    for (int i = lane; i < HROW; i += 64) { rowA[i] = 0; rowB[i] = 0; }
+    const uint32_t nslide = slide_count(n);
+    uint32_t curBlk = 0xffffffffu;
+
+    for (int ti = 0; ti < TILES_PER_SEG; ti++) {
+        const uint32_t t0 = g * SEG + ti * TILE;
+        if (t0 >= n) break;
+        const int len = (int)((n - t0) < (uint32_t)TILE ? (n - t0) : (uint32_t)TILE);
+        stage_tile(cin, t0, (uint32_t)len, mask, unmasked, lds);
+        __syncthreads();
+        const uint8_t *plane = lds + w * PLANE_LDS;
+        const TileInfo tinf = tinfo[(size_t)s * TPS + (t0 / TILE)];
+        if (curBlk == 0xffffffffu) curBlk = tinf.P / BLK_SYMS;
+        uint32_t x[16];
+        lane_row(plane, lane, x);
+        const LaneTile lt = analyse_lane(x, lane, len, tinf.B, tinf.F);
+        const LaneCls cls = classify_lane(lt.E, lt.a, lt.prevS, lt.nextS);
+        const uint64_t S = cls.S & lt.V, M = cls.M & lt.V;
+        const int cntl = popc64(S);
+        uint32_t tot;
+        const uint32_t base = tinf.P + wave_excl_sum((uint32_t)cntl, &tot);
+        /* block starts: a symbol whose index is a multiple of 32767 opens a block */
+        {
+            const uint32_t mb = ((base + BLK_SYMS - 1) / BLK_SYMS) * BLK_SYMS;
+            if (mb < base + (uint32_t)cntl) {
+                const int bit = select64(S, (int)(mb - base));
+                blkstart[(size_t)s * (MAXBLK + 1) + mb / BLK_SYMS] = t0 + (uint32_t)(lt.a + bit);
+            }
+        }
+        /* window-slide positions whose threshold lies in this tile (App. B.4): steady thresholds are
+         * 32768 apart, so at most one of them plus the final exhausted-state one can fall in a tile */
+        if (nslide) {
+            const uint32_t js = n >= 65536u ? n / 32768u - 1u : 0u;
+            uint32_t cand[2];
+            cand[0] = (t0 + 258u + 32767u) / 32768u; /* smallest k+1 with 32768 (k+1) - 258 >= t0 */
+            cand[0] = cand[0] >= 2u ? cand[0] - 1u : 1u;
+            if (cand[0] > js) cand[0] = 0;
+            cand[1] = nslide > js ? nslide : 0u;
+            for (int ci = 0; ci < 2; ci++) {
+                const uint32_t k = cand[ci];
+                if (!k) continue;
+                const uint32_t T = slide_threshold(n, k);
+                if (T < t0 || T >= t0 + (uint32_t)len) continue;
+                const int p = (int)(T - t0);
+                if (p >= lt.a && p < lt.a + 64)
+                    slideq[(size_t)s * MAXSLIDE + k] = t0 + (uint32_t)token_boundary_at(lt, cls, p);
+            }
+        }
+        /* split of this lane's symbols between the current block (row A) and the next (row B) */
+        const uint32_t nextBnd = (curBlk + 1u) * BLK_SYMS;
+        uint64_t inA;
+        if (base + (uint32_t)cntl <= nextBnd) inA = ~0ull;
+        else if (base >= nextBnd) inA = 0ull;
+        else {
+            const int q = select64(S, (int)(nextBnd - base));
+            inA = (1ull << q) - 1ull;
+        }
+        /* literals */
+        {
+            uint64_t m = S & ~M;
+            const uint8_t *row = plane + lane * ROWPAD;
+            while (m) {
+                const int i = ctz64(m);
+                m &= m - 1;
+                uint32_t *r = ((inA >> i) & 1ull) ? rowA : rowB;
+                atomicAdd(&r[row[i]], 1u);
+            }
+        }
+        /* matches */
+        {
+            uint64_t m = M;
+            while (m) {
+                const int i = ctz64(m);
+                m &= m - 1;
+                const int ml = match_len_at(lt.E, lt.a, lt.nextS, i);
+                int xb, xv;
+                const int code = len_code(ml, &xb, &xv);
+                uint32_t *r = ((inA >> i) & 1ull) ? rowA : rowB;
+                atomicAdd(&r[257 + code], 1u);
+                atomicAdd(&r[286], 1u);
+            }
+        }
+        __syncthreads(); /* all waves done with lds (and this wave's row updates are complete) */
+        /* crossed (or exactly reached) the block boundary: retire row A */
+        if (tinf.P + tot >= nextBnd) {
+            uint16_t *dst = pairhist + ((size_t)s * MAXPAIR + (g + curBlk)) * HROW;
+            for (int i = lane; i < HROW; i += 64) {
+                dst[i] = (uint16_t)rowA[i];
+                rowA[i] = rowB[i];
+                rowB[i] = 0;
+            }
+            curBlk++;
+        }
+    }
+    /* segment end: always retire the open row (possibly empty) so every pair (g, b) with
+     * b in [blk(P_g), blk(P_{g+1})] exists */
+    {
+        uint16_t *dst = pairhist + ((size_t)s * MAXPAIR + (g + curBlk)) * HROW;
+        for (int i = lane; i < HROW; i += 64) dst[i] = (uint16_t)rowA[i];
+    }
+}
+
+/* ======================================================================================
+ * block histograms = sum of the block's pairs
+ * ==================================================================================== */
+__global__ __launch_bounds__(64) void k_block_reduce(const TileInfo *__restrict__ tinfo, const StreamInfo *__restrict__ sinfo,
+                                                     const uint16_t *__restrict__ pairhist, uint16_t *__restrict__ blkfreq)
+{
+    const uint32_t b = blockIdx.x, s = blockIdx.y;
+    const StreamInfo si = sinfo[s];
+    if (b >= si.nblk) return;
+    const int lane = lane_id();
+    /* segments g with  Pseg[g] < 32767 (b+1)  and  Pseg[g+1] >= 32767 b   (Pseg[nseg] = nsym) */
+    const uint32_t lo = b * BLK_SYMS, hi = (b + 1u) * BLK_SYMS;
+    const TileInfo *ti = tinfo + (size_t)s * TPS;
+    /* gLast = max g with Pseg[g] < hi ; gFirst = min g with Pseg[g+1] >= lo */
+    int gl = 0, gf = 0;
+    {
+        int a = 0, z = (int)si.nseg - 1; /* Pseg monotone non-decreasing */
+        while (a < z) {
+            const int m = (a + z + 1) >> 1;
+            if (ti[m * TILES_PER_SEG].P < hi) a = m; else z = m - 1;
+        }
+        gl = a;
+        a = 0;
+        z = (int)si.nseg - 1;
+        while (a < z) {
+            const int m = (a + z) >> 1;
+            const uint32_t pn = (m + 1 < (int)si.nseg) ? ti[(m + 1) * TILES_PER_SEG].P : si.nsym;
+            if (pn >= lo) z = m; else a = m + 1;
+        }
+        gf = a;
+    }
+    uint32_t acc[5] = {0, 0, 0, 0, 0};
+    for (int g = gf; g <= gl; g++) {
+        const uint16_t *src = pairhist + ((size_t)s * MAXPAIR + (g + b)) * HROW;
+        for (int k = 0; k < 5; k++) {
+            const int i = lane + 64 * k;
+            if (i < HROW) acc[k] += src[i];
+        }
+    }
+    uint16_t *dst = blkfreq + ((size_t)s * MAXBLK + b) * HROW;
+    for (int k = 0; k < 5; k++) {
+        const int i = lane + 64 * k;
+        if (i < HROW) dst[i] = (uint16_t)acc[k];
+    }
+}
+
+/* ======================================================================================
+ * stream layout: block types, bit offsets, RAW decision  (one workgroup of 64 per stream)
+ * ==================================================================================== */
+__global__ __launch_bounds__(64) void k_stream_layout(StreamInfo *__restrict__ sinfo, const BlkMeta *__restrict__ meta,
+                                                      const uint32_t *__restrict__ blkstart,
+                                                      const uint32_t *__restrict__ slideq, BlkLay *__restrict__ lay)
+{
+    __shared__ uint32_t s_opt[MAXBLK], s_stat[MAXBLK], s_hdr[MAXBLK], s_start[MAXBLK + 1], s_q[MAXSLIDE];
+    const uint32_t s = blockIdx.x;
+    StreamInfo si = sinfo[s];
+    const int lane = lane_id();
+    const uint32_t nslide = slide_count(si.n);
+    for (uint32_t i = lane; i < si.nblk; i += 64) {
+        const BlkMeta m = meta[(size_t)s * MAXBLK + i];
+        s_opt[i] = m.opt_len; s_stat[i] = m.static_len; s_hdr[i] = m.hdr_bits;
+    }
+    for (uint32_t i = lane; i <= si.nblk; i += 64) s_start[i] = blkstart[(size_t)s * (MAXBLK + 1) + i];
+    for (uint32_t i = lane; i <= nslide; i += 64) s_q[i] = i ? slideq[(size_t)s * MAXSLIDE + i] : 0u;
+    __syncthreads();
+    if (lane != 0) return;
+    uint32_t bit = 0;
+    uint32_t k = 1; /* next slide to account for */
+    for (uint32_t b = 0; b < si.nblk; b++) {
+        const uint32_t start = s_start[b], end = s_start[b + 1];
+        const bool full = (b + 1 < si.nblk) || (si.nsym == si.nblk * BLK_SYMS);
+        /* slides that happened before this block was flushed: in-loop flush sees q_k < end,
+         * the final partial block is flushed after the loop and sees all of them */
+        while (k <= nslide && (full ? s_q[k] < end : true)) k++;
+        const uint32_t base = 32768u * (k - 1u);
+        const bool stored_ok = start >= base;
+        const uint32_t opt_len = s_opt[b], static_len = s_stat[b];
+        uint32_t opt_lenb = (opt_len + 3u + 7u) >> 3;
+        const uint32_t static_lenb = (static_len + 3u + 7u) >> 3;
+        if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+        const uint32_t stored_len = end - start;
+        BlkLay L;
+        L.bitpos = bit;
+        if (stored_len + 4u <= opt_lenb && stored_ok) {
+            L.btype = 0;
+            const uint32_t db = ((bit + 3u + 7u) & ~7u) + 32u; /* type bits, pad, LEN, NLEN */
+            L.databit = db;
+            bit = db + 8u * stored_len;
+        } else if (static_lenb == opt_lenb) {
+            L.btype = 1;
+            L.databit = bit + 3u;
+            bit += 3u + static_len;
+        } else {
+            L.btype = 2;
+            L.databit = bit + 3u + s_hdr[b];
+            bit += 3u + opt_len;
+        }
+        L.endbit = bit;
+        lay[(size_t)s * MAXBLK + b] = L;
+    }
+    si.zbits = bit;
+    const uint32_t zlen = ((bit + 3u + 7u) >> 3) + 4u; /* 000, pad, 00 00 FF FF */
+    si.zlen = zlen;
+    /* zip.c:170-177: zlib's output is capped at avail_out = chk, then COMPRESSED iff inlen > len + 4 */
+    const uint32_t len = zlen > CHK ? CHK : zlen;
+    si.raw = (si.n > len + 4u) ? 0u : 1u;
+    si.paylen = si.raw ? si.n : zlen;
+    sinfo[s] = si;
+}
+
+/* ======================================================================================
+ * pair bit counts and offsets
+ * ==================================================================================== */
+__global__ __launch_bounds__(64) void k_pair_bits(const StreamInfo *__restrict__ sinfo, const BlkLay *__restrict__ lay,
+                                                  const uint16_t *__restrict__ pairhist, const uint32_t *__restrict__ blkcode,
+                                                  const TileInfo *__restrict__ tinfo, uint32_t *__restrict__ pairbits)
+{
+    /* one wave per (segment, stream); handles the <= 3 blocks the segment touches */
+    const uint32_t g = blockIdx.x, s = blockIdx.y;
+    const StreamInfo si = sinfo[s];
+    if (g >= si.nseg) return;
+    const int lane = lane_id();
+    const TileInfo *ti = tinfo + (size_t)s * TPS;
+    const uint32_t p0 = ti[g * TILES_PER_SEG].P;
+    const uint32_t p1 = (g + 1 < si.nseg) ? ti[(g + 1) * TILES_PER_SEG].P : si.nsym;
+    const uint32_t b0 = p0 / BLK_SYMS, b1 = p1 / BLK_SYMS;
+    for (uint32_t b = b0; b <= b1; b++) {
+        uint32_t bits = 0;
+        if (b < si.nblk && si.raw == 0) {
+            const uint32_t bt = lay[(size_t)s * MAXBLK + b].btype;
+            if (bt != 0) {
+                const uint16_t *h = pairhist + ((size_t)s * MAXPAIR + (g + b)) * HROW;
+                const uint32_t *code = blkcode + ((size_t)s * MAXBLK + b) * HROW;
+                for (int k = 0; k < 5; k++) {
+                    const int i = lane + 64 * k;
+                    if (i < 286) {
+                        const uint32_t f = h[i];
+                        uint32_t l = (bt == 2) ? (code[i] >> 16) : (uint32_t)static_llen(i);
+                        if (i >= 257) l += (uint32_t)len_extra_bits(i - 257) + (bt == 2 ? 1u : 5u); /* + distance code */
+                        bits += f * l;
+                    }
+                }
+            }
+        }
+        bits = wave_sum_u(bits);
+        if (lane == 0) pairbits[(size_t)s * MAXPAIR + (g + b)] = bits;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_pair_offsets(const StreamInfo *__restrict__ sinfo, const BlkLay *__restrict__ lay,
+                                                     const TileInfo *__restrict__ tinfo, const uint32_t *__restrict__ pairbits,
+                                                     uint32_t *__restrict__ pairoff)
+{
+    __shared__ uint32_t s_pb[MAXPAIR];
+    __shared__ uint32_t s_pseg[SPS + 1];
+    __shared__ uint32_t s_db[MAXBLK];
+    const uint32_t s = blockIdx.x;
+    const StreamInfo si = sinfo[s];
+    const int lane = lane_id();
+    const TileInfo *ti = tinfo + (size_t)s * TPS;
+    for (uint32_t g = lane; g < si.nseg; g += 64) s_pseg[g] = ti[g * TILES_PER_SEG].P;
+    if (lane == 0) s_pseg[si.nseg] = si.nsym;
+    for (uint32_t i = lane; i < si.nseg + si.nblk + 1 && i < (uint32_t)MAXPAIR; i += 64) s_pb[i] = pairbits[(size_t)s * MAXPAIR + i];
+    for (uint32_t b = lane; b < si.nblk; b += 64) s_db[b] = lay[(size_t)s * MAXBLK + b].databit;
+    __syncthreads();
+    if (lane != 0) return;
+    uint32_t *po = pairoff + (size_t)s * MAXPAIR;
+    uint32_t g = 0, b = 0;
+    uint32_t off = si.nblk ? s_db[0] : 0u;
+    for (;;) {
+        po[g + b] = off;
+        const uint32_t bend = s_pseg[g + 1] / BLK_SYMS; /* last block this segment touches */
+        if (b < bend) {
+            b++;
+            off = b < si.nblk ? s_db[b] : 0u;
+        } else {
+            off += s_pb[g + b];
+            g++;
+            if (g >= si.nseg) break;
+        }
+    }
+}
+
+/* ======================================================================================
+ * container layout: payload offsets + the 16-byte chunk headers (workers.c:837-842, zip.c:381-391)
+ * ==================================================================================== */
+__global__ __launch_bounds__(256) void k_container(StreamInfo *__restrict__ sinfo, uint32_t nchunks, uint8_t *__restrict__ out,
+                                                   uint64_t *__restrict__ result /* [0] running byte offset, [1..4] per-plane zfsz */)
+{
+    /* one thread per chunk of the batch (<= 128 chunks, records < 4 GiB) */
+    __shared__ SegPair wsum[4];
+    const uint32_t c = threadIdx.x;
+    uint32_t len[4] = {0, 0, 0, 0}, raw[4] = {0, 0, 0, 0};
+    SegPair v;
+    v.sum = 0;
+    v.brk = 0;
+    if (c < nchunks) {
+        for (int j = 0; j < 4; j++) {
+            len[j] = sinfo[4 * c + j].paylen;
+            raw[j] = sinfo[4 * c + j].raw;
+        }
+        v.sum = 16u + len[0] + len[1] + len[2] + len[3];
+    }
+    const uint64_t base = result[0];
+    const SegPair pre = block_excl_scan(v, wsum);
+    if (c < nchunks) {
+        const uint64_t off = base + pre.sum;
+        uint64_t p = off + 16;
+        for (int j = 0; j < 4; j++) {
+            uint8_t *h = out + off + 4u * j;   /* pack_header, zip.c:381-391 */
+            h[0] = (uint8_t)(len[j] & 0xff);
+            h[1] = (uint8_t)((len[j] >> 8) & 0xff);
+            h[2] = (uint8_t)((len[j] >> 16) & 0xff);
+            h[3] = (uint8_t)(((len[j] >> 24) & 0x7f) | (raw[j] << 7));
+            sinfo[4 * c + j].payoff = p;
+            p += len[j];
+            atomicAdd((unsigned long long *)&result[1 + j], (unsigned long long)len[j] + 4ull);
+        }
+    }
+    __syncthreads();
+    if (c + 1 == nchunks) result[0] = base + pre.sum + v.sum;
+}
+
+/* ======================================================================================
+ * emit
+ * ==================================================================================== */
+constexpr int STAGE_WORDS = 2048; /* 8 KiB per wave: 4096 symbols x <= 15 bits = 7680 B + alignment */
+
+/* OR `nbits` (<= 32) bits of `val` into the bit string at absolute bit position `pos` of a zeroed
+ * device buffer (32-bit atomics: neighbouring writers share boundary words) */
+__device__ __forceinline__ void global_or_bits(uint32_t *out32, uint64_t pos, uint32_t val, int nbits)
+{
+    if (nbits <= 0) return;
+    const uint64_t wi = pos >> 5;
+    const int sh = (int)(pos & 31u);
+    const uint64_t v = (uint64_t)(nbits >= 32 ? val : (val & ((1u << nbits) - 1u))) << sh;
+    if ((uint32_t)v) atomicOr(&out32[wi], (uint32_t)v);
+    if ((uint32_t)(v >> 32)) atomicOr(&out32[wi + 1], (uint32_t)(v >> 32));
+}
+
+/* per-lane bit accumulator flushing into the wave's LDS staging buffer */
+struct LanePacker {
+    uint32_t *stage;
+    uint64_t acc;
+    int nacc;       /* bits held in acc */
+    uint32_t word;  /* staging word index the low bits of acc belong to */
+    int covered;    /* bits of that word that lie before acc's first bit (owned by an earlier lane) */
+};
+__device__ __forceinline__ void packer_init(LanePacker &p, uint32_t *stage, uint32_t bitpos)
+{
+    p.stage = stage;
+    p.word = bitpos >> 5;
+    p.covered = (int)(bitpos & 31u);
+    p.acc = 0;
+    p.nacc = 0;
+}
+__device__ __forceinline__ void packer_put(LanePacker &p, uint32_t val, int nbits)
+{
+    p.acc |= (uint64_t)val << (p.covered + p.nacc);
+    p.nacc += nbits;
+    if (p.covered + p.nacc >= 32) {
+        const uint32_t wv = (uint32_t)p.acc;
+        if (p.covered == 0) p.stage[p.word] = wv;      /* this lane owns all 32 bits */
+        else atomicOr(&p.stage[p.word], wv);
+        p.acc >>= 32;
+        p.nacc -= 32 - p.covered;
+        p.covered = 0;
+        p.word++;
+    }
+}
+__device__ __forceinline__ void packer_finish(LanePacker &p)
+{
+    if (p.nacc > 0) atomicOr(&p.stage[p.word], (uint32_t)p.acc);
+}
+
+__global__ __launch_bounds__(256) void k_emit(const uint32_t *__restrict__ in, uint64_t nfloats, uint32_t mask,
+                                              uint32_t first_chunk_is_file_start, const TileInfo *__restrict__ tinfo,
+                                              const StreamInfo *__restrict__ sinfo, const BlkLay *__restrict__ lay,
+                                              const uint32_t *__restrict__ blkstart, const uint32_t *__restrict__ blkcode,
+                                              const uint32_t *__restrict__ pairoff, uint8_t *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PLANE_LDS];
+    __shared__ __attribute__((aligned(16))) uint32_t stage_all[4][STAGE_WORDS];
+    __shared__ uint32_t lut_all[4][HROW];
+    const uint32_t g = blockIdx.x, c = blockIdx.y;
+    const uint64_t cbase = (uint64_t)c * CHK;
+    const uint32_t n = (uint32_t)((nfloats - cbase) < CHK ? (nfloats - cbase) : CHK);
+    if ((uint64_t)g * SEG >= n) return;
+    const uint32_t *cin = in + cbase;
+    const uint32_t unmasked = (c == 0 && first_chunk_is_file_start) ? 256u : 0u;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const uint32_t s = 4u * c + (uint32_t)w;
+    const StreamInfo si = sinfo[s];
+    uint32_t *stage = stage_all[w];
+    uint32_t *lut = lut_all[w];
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    const uint64_t paybit = si.payoff * 8ull;
+    const uint32_t *bstart = blkstart + (size_t)s * (MAXBLK + 1);
+    const BlkLay *blay = lay + (size_t)s * MAXBLK;
+
+    uint32_t curBlk = 0xffffffffu;
+    uint32_t cur = 0;        /* stream bit offset where the next symbol of the current block goes */
+    int mode = -1;           /* 0 stored, 1 static, 2 dynamic, 3 raw stream */
+    uint32_t blkEnd = 0;     /* position where the current block ends */
+    uint32_t dbits = 0;      /* distance-code bits per match (1 dynamic, 5 static) */
+
+    for (int ti = 0; ti < TILES_PER_SEG; ti++) {
+        const uint32_t t0 = g * SEG + ti * TILE;
+        if (t0 >= n) break;
+        const int len = (int)((n - t0) < (uint32_t)TILE ? (n - t0) : (uint32_t)TILE);
+        stage_tile(cin, t0, (uint32_t)len, mask, unmasked, lds);
+        __syncthreads();
+        const uint8_t *plane = lds + w * PLANE_LDS;
+        const uint8_t *row = plane + lane * ROWPAD;
+        const TileInfo tinf = tinfo[(size_t)s * TPS + (t0 / TILE)];
+        uint32_t x[16];
+        lane_row(plane, lane, x);
+        const LaneTile lt = analyse_lane(x, lane, len, tinf.B, tinf.F);
+        const LaneCls cls = classify_lane(lt.E, lt.a, lt.prevS, lt.nextS);
+
+        if (si.raw) {
+            /* RAW plane (zip.c:184-190): the payload is the plane bytes themselves */
+            if (mode != 3) {
+                mode = 3;
+                for (int i = lane; i < 256; i += 64) lut[i] = (uint32_t)i | (8u << 16);
+                blkEnd = n;
+                __builtin_amdgcn_wave_barrier();
+            }
+            cur = 8u * t0;
+        } else if (curBlk == 0xffffffffu) {
+            curBlk = tinf.P / BLK_SYMS;
+            if (bstart[curBlk] > t0) curBlk--; /* the tile starts inside the previous block's last match */
+            mode = -1;
+        }
+
+        /* a tile may straddle one block boundary: process [part 0 | part 1] */
+        int pos0 = 0; /* tile-relative start of the part */
+        for (int part = 0; part < 2 && pos0 < len; part++) {
+            if (!si.raw) {
+                if (mode < 0 || t0 + (uint32_t)pos0 >= blkEnd) {
+                    if (mode >= 0) curBlk++;
+                    const BlkLay L = blay[curBlk];
+                    mode = (int)L.btype;
+                    blkEnd = bstart[curBlk + 1];
+                    if (mode == 0) {
+                        for (int i = lane; i < 256; i += 64) lut[i] = (uint32_t)i | (8u << 16);
+                        cur = L.databit + 8u * (t0 + (uint32_t)pos0 - bstart[curBlk]);
+                    } else {
+                        if (mode == 2) {
+                            const uint32_t *code = blkcode + ((size_t)s * MAXBLK + curBlk) * HROW;
+                            for (int i = lane; i < 286; i += 64) lut[i] = code[i];
+                            dbits = 1;
+                        } else {
+                            for (int i = lane; i < 286; i += 64) {
+                                int l;
+                                const uint32_t cd = static_lcode(i, &l);
+                                lut[i] = cd | ((uint32_t)l << 16);
+                            }
+                            dbits = 5;
+                        }
+                        cur = pairoff[(size_t)s * MAXPAIR + (g + curBlk)];
+                    }
+                    __builtin_amdgcn_wave_barrier(); /* lut visible to the whole wave */
+                }
+            }
+            int pos1 = len; /* tile-relative end of the part */
+            if (blkEnd < t0 + (uint32_t)len) pos1 = (int)(blkEnd - t0);
+            /* lane-relative part mask */
+            const int lo = pos0 - lt.a, hi = pos1 - lt.a;
+            const uint64_t mlo = lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+            const uint64_t mhi = hi >= 64 ? ~0ull : (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
+            const uint64_t pm = mlo & mhi & lt.V;
+            const bool bytes_mode = (mode == 0 || mode == 3);
+            const uint64_t S = bytes_mode ? pm : (cls.S & pm);
+            const uint64_t M = bytes_mode ? 0ull : (cls.M & pm);
+
+            /* pass A: bits produced by this lane */
+            uint32_t lbits = 0;
+            if (bytes_mode) lbits = 8u * (uint32_t)popc64(S);
+            else {
+                uint64_t m = S & ~M;
+                while (m) { const int i = ctz64(m); m &= m - 1; lbits += lut[row[i]] >> 16; }
+                m = M;
+                while (m) {
+                    const int i = ctz64(m); m &= m - 1;
+                    int xb, xv;
+                    const int code = len_code(match_len_at(lt.E, lt.a, lt.nextS, i), &xb, &xv);
+                    lbits += (lut[257 + code] >> 16) + (uint32_t)xb + dbits;
+                }
+            }
+            uint32_t tot;
+            const uint32_t lofs = wave_excl_sum(lbits, &tot);
+            if (tot) {
+                /* staging buffer: bit 0 of stage word 0 = global bit (gbit & ~31) */
+                const uint64_t gbit = paybit + cur;
+                const uint32_t lead = (uint32_t)(gbit & 31u);
+                const uint32_t nwords = (lead + tot + 31u) >> 5;
+                for (uint32_t i = lane; i < nwords; i += 64) stage[i] = 0;
+                __builtin_amdgcn_wave_barrier();
+                LanePacker pk;
+                packer_init(pk, stage, lead + lofs);
+                {
+                    uint64_t m = S;
+                    while (m) {
+                        const int i = ctz64(m);
+                        m &= m - 1;
+                        if ((M >> i) & 1ull) {
+                            int xb, xv;
+                            const int code = len_code(match_len_at(lt.E, lt.a, lt.nextS, i), &xb, &xv);
+                            const uint32_t e = lut[257 + code];
+                            const int cl = (int)(e >> 16);
+                            packer_put(pk, (e & 0xffffu) | ((uint32_t)xv << cl), cl + xb + (int)dbits);
+                        } else {
+                            const uint32_t e = lut[row[i]];
+                            packer_put(pk, e & 0xffffu, (int)(e >> 16));
+                        }
+                    }
+                }
+                packer_finish(pk);
+                __builtin_amdgcn_wave_barrier();
+                const uint64_t w0 = gbit >> 5;
+                for (uint32_t i = lane; i < nwords; i += 64) {
+                    const uint32_t v = stage[i];
+                    if (i == 0 || i == nwords - 1) { if (v) atomicOr(&out32[w0 + i], v); }
+                    else out32[w0 + i] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                cur += tot;
+            }
+            pos0 = pos1;
+        }
+        __syncthreads();
+    }
+}
+
+/* ======================================================================================
+ * block headers, END_BLOCK codes, sync markers
+ * ==================================================================================== */
+__global__ __launch_bounds__(64) void k_emit_headers(const StreamInfo *__restrict__ sinfo, const BlkLay *__restrict__ lay,
+                                                     const BlkMeta *__restrict__ meta, const uint32_t *__restrict__ blkhdr,
+                                                     const uint32_t *__restrict__ blkstart, uint8_t *__restrict__ out)
+{
+    const uint32_t b = blockIdx.x, s = blockIdx.y;
+    const StreamInfo si = sinfo[s];
+    if (si.raw || b > si.nblk) return;
+    const int lane = lane_id();
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    const uint64_t paybit = si.payoff * 8ull;
+    if (b == si.nblk) {
+        /* Z_FULL_FLUSH marker: 000, pad to byte, 00 00 FF FF (App. B.1) */
+        if (lane == 0) {
+            const uint32_t mb = ((si.zbits + 3u + 7u) & ~7u) + 16u;
+            global_or_bits(out32, paybit + mb, 0xffffu, 16);
+        }
+        return;
+    }
+    const BlkLay L = lay[(size_t)s * MAXBLK + b];
+    const BlkMeta m = meta[(size_t)s * MAXBLK + b];
+    if (L.btype == 0) {
+        if (lane == 0) {
+            const uint32_t slen = blkstart[(size_t)s * (MAXBLK + 1) + b + 1] - blkstart[(size_t)s * (MAXBLK + 1) + b];
+            /* type bits 000 are already zero; LEN, NLEN sit right before the data */
+            global_or_bits(out32, paybit + L.databit - 32u, (slen & 0xffffu) | ((~slen & 0xffffu) << 16), 32);
+        }
+        return;
+    }
+    if (L.btype == 1) {
+        if (lane == 0) {
+            global_or_bits(out32, paybit + L.bitpos, 2u, 3);
+            int l;
+            const uint32_t cd = static_lcode(256, &l);
+            global_or_bits(out32, paybit + L.endbit - (uint32_t)l, cd, l);
+        }
+        return;
+    }
+    /* dynamic: 3 type bits + header bit string + END_BLOCK at the end */
+    if (lane == 0) {
+        global_or_bits(out32, paybit + L.bitpos, 4u, 3);
+        global_or_bits(out32, paybit + L.endbit - (m.eob >> 16), m.eob & 0xffffu, (int)(m.eob >> 16));
+    }
+    const uint32_t *h = blkhdr + ((size_t)s * MAXBLK + b) * HDRWORDS;
+    const uint32_t nw = (m.hdr_bits + 31u) >> 5;
+    for (uint32_t i = lane; i < nw; i += 64) {
+        const uint32_t nb = (i + 1 == nw) ? (m.hdr_bits - 32u * i) : 32u;
+        global_or_bits(out32, paybit + L.bitpos + 3u + 32u * i, h[i], (int)nb);
+    }
+}
+
+} /* namespace mrcz */

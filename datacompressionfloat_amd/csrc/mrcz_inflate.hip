@@ -1,0 +1,283 @@
+/*
+ * mrcz_inflate.hip -- gfx950 kernels of the decompressor.
+ *
+ * Replaces uncompress_byte_stream + mzlib_inf (/root/reference/src/core/workers.c:52-80,
+ * src/core/zip.c:262-284: one raw inflate per plane per chunk, or RAW passthrough) and
+ * merge_byte_to_float_stream (workers.c:423-442).  Every (chunk, plane) payload is an independent
+ * raw-deflate stream (each ends on a Z_FULL_FLUSH boundary and its first symbol is a literal), so
+ * streams are decoded concurrently, one wave per stream.
+ *
+ *   k_parse_records  walks the 16-byte chunk headers (unpack_header, zip.c:393-399)
+ *   k_inflate        v1: lane 0 of each wave decodes its stream sequentially (general DEFLATE:
+ *                    stored / fixed / dynamic blocks, any distance), RAW planes are copied by the
+ *                    whole wave
+ *   k_merge_planes   4 byte planes -> float words (uint4 stores)
+ */
+#include "mrcz_common.h"
+
+namespace mrcz {
+
+struct DecStream {
+    uint64_t payoff;
+    uint32_t paylen;
+    uint32_t raw;
+    uint32_t n;      /* plane bytes to produce */
+    uint32_t pad;
+};
+
+__global__ void k_parse_records(const uint8_t *__restrict__ rec, uint64_t len, uint64_t nfloats, uint32_t chk,
+                                DecStream *__restrict__ ds, uint64_t *__restrict__ result /* [0] consumed, [1] error */)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t off = 0;
+    uint64_t err = 0;
+    const uint64_t nchunks = (nfloats + chk - 1) / chk;
+    for (uint64_t c = 0; c < nchunks; c++) {
+        const uint64_t left = nfloats - c * chk;
+        const uint32_t n = (uint32_t)(left < chk ? left : chk);
+        if (off + 16 > len) { err = 1; break; }
+        uint64_t p = off + 16;
+        for (int j = 0; j < 4; j++) {
+            const uint8_t *h = rec + off + 4 * j;
+            const uint32_t raw = (h[3] & 0x80u) >> 7;
+            const uint32_t l = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)(h[3] & 0x7fu) << 24);
+            DecStream d;
+            d.payoff = p; d.paylen = l; d.raw = raw; d.n = n; d.pad = 0;
+            if (p + l > len || (raw && l < n)) err = 1;
+            ds[4 * c + j] = d;
+            p += l;
+        }
+        if (err) break;
+        off = p;
+    }
+    result[0] = off;
+    result[1] = err;
+}
+
+/* ---- sequential bit reader over global memory (lane 0 only) ---- */
+struct BitReader {
+    const uint8_t *in;
+    uint32_t len;
+    uint32_t pos;
+    uint64_t acc;
+    int nacc;
+};
+__device__ __forceinline__ void br_fill(BitReader &r)
+{
+    while (r.nacc <= 56 && r.pos < r.len) {
+        r.acc |= (uint64_t)r.in[r.pos++] << r.nacc;
+        r.nacc += 8;
+    }
+}
+__device__ __forceinline__ uint32_t br_peek(BitReader &r, int n) { return (uint32_t)(r.acc & ((1ull << n) - 1ull)); }
+__device__ __forceinline__ void br_drop(BitReader &r, int n) { r.acc >>= n; r.nacc -= n; }
+__device__ __forceinline__ uint32_t br_get(BitReader &r, int n)
+{
+    if (n == 0) return 0;
+    if (r.nacc < n) br_fill(r);
+    const uint32_t v = br_peek(r, n);
+    br_drop(r, n);
+    return v;
+}
+
+constexpr int LUTBITS = 9;
+
+/* canonical-Huffman decoding tables: fast LUT for codes <= 9 bits, count/symbol arrays for the rest */
+struct DecTable {
+    uint16_t lut[1 << LUTBITS]; /* sym | len << 12 (len 0 = not in LUT) */
+    uint16_t count[16];
+    uint16_t symbol[288];
+};
+
+__device__ void build_table(DecTable &t, const uint8_t *lens, int n)
+{
+    uint16_t offs[16];
+    for (int i = 0; i < 16; i++) t.count[i] = 0;
+    for (int i = 0; i < n; i++) t.count[lens[i]]++;
+    t.count[0] = 0;
+    offs[1] = 0;
+    for (int i = 1; i < 15; i++) offs[i + 1] = (uint16_t)(offs[i] + t.count[i]);
+    for (int i = 0; i < n; i++)
+        if (lens[i]) t.symbol[offs[lens[i]]++] = (uint16_t)i;
+    for (int i = 0; i < (1 << LUTBITS); i++) t.lut[i] = 0;
+    /* canonical codes -> LUT entries (codes are read LSB-first, i.e. bit-reversed) */
+    uint32_t code = 0;
+    int idx = 0;
+    for (int l = 1; l <= 15; l++) {
+        for (int k = 0; k < t.count[l]; k++, idx++) {
+            if (l <= LUTBITS) {
+                const uint32_t rev = __brev(code) >> (32 - l);
+                for (uint32_t fill = rev; fill < (1u << LUTBITS); fill += (1u << l))
+                    t.lut[fill] = (uint16_t)(t.symbol[idx] | (l << 12));
+            }
+            code++;
+        }
+        code <<= 1;
+    }
+}
+
+__device__ __forceinline__ int decode_sym(BitReader &r, const DecTable &t)
+{
+    if (r.nacc < 15) br_fill(r);
+    const uint32_t e = t.lut[br_peek(r, LUTBITS)];
+    if (e) {
+        const int l = (int)(e >> 12);
+        if (l > r.nacc) return -1;
+        br_drop(r, l);
+        return (int)(e & 0xfffu);
+    }
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= 15; l++) {
+        if (r.nacc < 1) return -1;
+        code |= (int)br_peek(r, 1);
+        br_drop(r, 1);
+        const int cnt = t.count[l];
+        if (code - cnt < first) return t.symbol[index + (code - first)];
+        index += cnt;
+        first += cnt;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -2;
+}
+
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ rec, const DecStream *__restrict__ ds,
+                                                uint8_t *__restrict__ planes, uint64_t *__restrict__ result)
+{
+    __shared__ DecTable tl, td;
+    __shared__ uint8_t lens[320];
+    const uint32_t s = blockIdx.x;
+    const DecStream d = ds[s];
+    uint8_t *out = planes + (size_t)s * CHK;
+    const int lane = lane_id();
+    if (d.raw) {
+        const uint8_t *src = rec + d.payoff;
+        for (uint32_t i = lane; i < d.n; i += 64) out[i] = src[i];
+        return;
+    }
+    if (lane != 0) return;
+    const uint16_t base_len[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    const uint16_t base_dist[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    BitReader r;
+    r.in = rec + d.payoff; r.len = d.paylen; r.pos = 0; r.acc = 0; r.nacc = 0;
+    uint32_t op = 0;
+    bool bad = false;
+    while (op < d.n && !bad) {
+        br_fill(r);
+        if (r.nacc < 3) break;
+        const uint32_t hdr = br_get(r, 3);
+        const int final = hdr & 1, type = (int)(hdr >> 1);
+        if (type == 0) {
+            br_drop(r, r.nacc & 7); /* to the byte boundary */
+            br_fill(r);
+            if (r.nacc < 32) break;
+            const uint32_t l = br_get(r, 16), nl = br_get(r, 16);
+            if ((l ^ 0xffffu) != nl) { bad = true; break; }
+            for (uint32_t i = 0; i < l && op < d.n; i++) {
+                if (r.nacc < 8) br_fill(r);
+                if (r.nacc < 8) { bad = true; break; }
+                out[op++] = (uint8_t)br_get(r, 8);
+            }
+        } else if (type == 1 || type == 2) {
+            if (type == 1) {
+                for (int i = 0; i < 288; i++) lens[i] = (uint8_t)static_llen(i);
+                build_table(tl, lens, 288);
+                for (int i = 0; i < 30; i++) lens[i] = 5;
+                build_table(td, lens, 30);
+            } else {
+                const int nlen = (int)br_get(r, 5) + 257, ndist = (int)br_get(r, 5) + 1, ncode = (int)br_get(r, 4) + 4;
+                if (nlen > 286 || ndist > 30) { bad = true; break; }
+                for (int i = 0; i < 19; i++) lens[i] = 0;
+                for (int i = 0; i < ncode; i++) lens[order[i]] = (uint8_t)br_get(r, 3);
+                build_table(tl, lens, 19); /* tl doubles as the code-length decoder */
+                int idx = 0;
+                while (idx < nlen + ndist) {
+                    const int sym = decode_sym(r, tl);
+                    if (sym < 0) { bad = true; break; }
+                    if (sym < 16) lens[idx++] = (uint8_t)sym;
+                    else {
+                        int rep, val = 0;
+                        if (sym == 16) {
+                            if (idx == 0) { bad = true; break; }
+                            val = lens[idx - 1];
+                            rep = 3 + (int)br_get(r, 2);
+                        } else if (sym == 17) rep = 3 + (int)br_get(r, 3);
+                        else rep = 11 + (int)br_get(r, 7);
+                        if (idx + rep > nlen + ndist) { bad = true; break; }
+                        while (rep--) lens[idx++] = (uint8_t)val;
+                    }
+                }
+                if (bad) break;
+                build_table(td, lens + nlen, ndist);
+                build_table(tl, lens, nlen);
+            }
+            for (;;) {
+                const int sym = decode_sym(r, tl);
+                if (sym < 0) { bad = true; break; }
+                if (sym < 256) {
+                    if (op >= d.n) { bad = true; break; }
+                    out[op++] = (uint8_t)sym;
+                } else if (sym == 256) break;
+                else {
+                    const int lc = sym - 257;
+                    if (lc >= 29) { bad = true; break; }
+                    const int xb = len_extra_bits(lc);
+                    uint32_t ml = base_len[lc] + br_get(r, xb);
+                    const int dsym = decode_sym(r, td);
+                    if (dsym < 0 || dsym >= 30) { bad = true; break; }
+                    const int dxb = dsym < 4 ? 0 : (dsym >> 1) - 1;
+                    const uint32_t dist = base_dist[dsym] + br_get(r, dxb);
+                    if (dist > op || op + ml > d.n) { bad = true; break; }
+                    for (uint32_t i = 0; i < ml; i++, op++) out[op] = out[op - dist];
+                }
+            }
+        } else bad = true;
+        if (final) break;
+    }
+    if (bad || op != d.n) atomicAdd((unsigned long long *)&result[1], 1ull);
+}
+
+/* merge_byte_to_float_stream (workers.c:423-442): planes[4c+j][i] -> byte j of word c*chk + i */
+__global__ __launch_bounds__(256) void k_merge_planes(const uint8_t *__restrict__ planes, uint64_t nfloats, uint32_t chk,
+                                                      uint32_t *__restrict__ out)
+{
+    const uint32_t c = blockIdx.y;
+    const uint64_t cbase = (uint64_t)c * chk;
+    const uint32_t n = (uint32_t)((nfloats - cbase) < chk ? (nfloats - cbase) : chk);
+    const uint8_t *p0 = planes + (size_t)(4 * c + 0) * CHK;
+    const uint8_t *p1 = planes + (size_t)(4 * c + 1) * CHK;
+    const uint8_t *p2 = planes + (size_t)(4 * c + 2) * CHK;
+    const uint8_t *p3 = planes + (size_t)(4 * c + 3) * CHK;
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; 4ull * q < n; q += gridDim.x * 256) {
+        const uint32_t i = 4 * q;
+        if (i + 4 <= n) {
+            const uint32_t a = *reinterpret_cast<const uint32_t *>(p0 + i);
+            const uint32_t b = *reinterpret_cast<const uint32_t *>(p1 + i);
+            const uint32_t cc = *reinterpret_cast<const uint32_t *>(p2 + i);
+            const uint32_t d = *reinterpret_cast<const uint32_t *>(p3 + i);
+            /* 4x4 byte transpose back */
+            const uint32_t ab_lo = __byte_perm(a, b, 0x5140), ab_hi = __byte_perm(a, b, 0x7362);
+            const uint32_t cd_lo = __byte_perm(cc, d, 0x5140), cd_hi = __byte_perm(cc, d, 0x7362);
+            uint4 v;
+            v.x = __byte_perm(ab_lo, cd_lo, 0x5410);
+            v.y = __byte_perm(ab_lo, cd_lo, 0x7632);
+            v.z = __byte_perm(ab_hi, cd_hi, 0x5410);
+            v.w = __byte_perm(ab_hi, cd_hi, 0x7632);
+            if (((cbase + i) & 3ull) == 0) *reinterpret_cast<uint4 *>(out + cbase + i) = v;
+            else { out[cbase + i] = v.x; out[cbase + i + 1] = v.y; out[cbase + i + 2] = v.z; out[cbase + i + 3] = v.w; }
+        } else {
+            for (uint32_t k = i; k < n; k++)
+                out[cbase + k] = (uint32_t)p0[k] | ((uint32_t)p1[k] << 8) | ((uint32_t)p2[k] << 16) | ((uint32_t)p3[k] << 24);
+        }
+    }
+}
+
+/* apply_mask alone (erasebytes restatement, src/tool/erasebytes.c:109-134) */
+__global__ __launch_bounds__(256) void k_erase_bits(uint32_t *__restrict__ w, uint64_t nwords, uint64_t first_word_index, uint32_t mask)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * 256)
+        if (first_word_index + i >= 256) w[i] &= mask;
+}
+
+} /* namespace mrcz */

@@ -1,0 +1,114 @@
+/*
+ * mrcz_hip.h -- C ABI of the MI355X (gfx950) float32 mask + byte-plane + DEFLATE(Z_RLE) codec.
+ *
+ * This is the device-level boundary that sits UNDER the reference's own chunk-codec seam
+ * (run_compress / run_uncompress, /root/reference/src/include/workers.h:30-31 -- see mrcz_workers.h
+ * for the drop-in replacement of that seam).  It replaces, for a batch of chunks that is already
+ * resident in HBM:
+ *
+ *   reference function                               file:line                      here
+ *   -----------------------------------------------  -----------------------------  ---------------------
+ *   apply_mask + split_float_to_byte_stream          src/core/workers.c:82-101,     mrcz_compress_chunks
+ *                                                    src/core/workers.c:180-203
+ *   mzlib_def (deflate(Z_FULL_FLUSH) per plane,      src/core/zip.c:164-196         mrcz_compress_chunks
+ *     RAW test, pack_header)                         src/core/zip.c:381-391
+ *   chunk record writer of run_compress              src/core/workers.c:837-850     mrcz_compress_chunks
+ *   uncompress_byte_stream + mzlib_inf               src/core/workers.c:52-80,      mrcz_uncompress_chunks
+ *                                                    src/core/zip.c:262-284
+ *   merge_byte_to_float_stream                       src/core/workers.c:423-442     mrcz_uncompress_chunks
+ *
+ * Plain pointers and sizes only; no torch types.  All device pointers are ordinary HIP device
+ * allocations (hipMalloc or a torch tensor's data_ptr()).  Functions return 0 on success and a
+ * negative MRCZ_E* code on failure; they never fall back to the CPU.
+ */
+#ifndef MRCZ_HIP_H_
+#define MRCZ_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRCZ_CHUNK_FLOATS 6291456u /* src/include/constant.h:25 CHUNK_SIZE */
+#define MRCZ_FILE_HEADER_BYTES 17  /* src/core/common.c:137-148 */
+
+#define MRCZ_OK 0
+#define MRCZ_EINVAL (-1)   /* bad argument (bits outside 0..32, NULL pointer, ...) */
+#define MRCZ_ENOMEM (-2)   /* device allocation failed */
+#define MRCZ_ECAP (-3)     /* output capacity too small */
+#define MRCZ_EFORMAT (-4)  /* malformed container / deflate stream */
+#define MRCZ_EHIP (-5)     /* HIP runtime error (see mrcz_last_error) */
+
+typedef struct mrcz_ctx mrcz_ctx_t;
+
+/* Create a codec context on HIP device `device` owning one stream and a workspace sized for
+ * batches of up to `max_batch_chunks` chunks (0 = default 64).  Thread-safety: one context per
+ * calling thread (the reference's workers call run_compress concurrently on different files,
+ * src/main/mrc_tarx.c:134-176; give each its own context). */
+int mrcz_create(mrcz_ctx_t **ctx, int device, uint32_t max_batch_chunks);
+void mrcz_destroy(mrcz_ctx_t *ctx);
+const char *mrcz_last_error(const mrcz_ctx_t *ctx);
+/* HIP stream (hipStream_t) all work of this context is enqueued on; for external event timing. */
+void *mrcz_stream(mrcz_ctx_t *ctx);
+
+/* Worst-case bytes of chunk records for nfloats input floats (16 B per chunk + 4 B per float). */
+uint64_t mrcz_records_bound(uint64_t nfloats);
+
+/*
+ * Compress `nfloats` float32 words that start a chunk boundary of a file.
+ *   d_in           device pointer, 16-byte aligned, nfloats 32-bit words
+ *   first_chunk    index within the FILE of the first chunk in d_in (chunk 0 keeps its first 256
+ *                  words unmasked, src/core/workers.c:90-94,777,804)
+ *   bits           low bits to erase, 0..32 (src/core/workers.c:29-37)
+ *   d_out          device pointer, receives the chunk records back to back exactly as
+ *                  run_compress writes them after the 17-byte file header
+ *                  (src/core/workers.c:837-850): 16-byte header + 4 payloads per chunk
+ *   out_cap        capacity of d_out in bytes (>= mrcz_records_bound(nfloats))
+ *   out_len        (host) total bytes written
+ *   plane_bytes    (host, optional, 4 x u64) per-plane sum of payload+4 bytes, i.e. what the
+ *                  reference accumulates in mzip_t.zfsz (src/core/zip.c:193-194)
+ * Synchronous with respect to the host on return (results are final).
+ */
+int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk,
+                         int bits, void *d_out, uint64_t out_cap, uint64_t *out_len,
+                         uint64_t plane_bytes[4]);
+
+/*
+ * Decompress chunk records (no file header) holding `nfloats` floats in chunks of `chk` floats
+ * (hd->chk, src/core/workers.c:577-578; only chk == MRCZ_CHUNK_FLOATS or a single smaller chunk
+ * layout is produced by the reference).
+ *   d_records/len  device pointer + byte length of the records
+ *   d_out          device pointer, 16-byte aligned, receives nfloats 32-bit words
+ *   consumed       (host, optional) bytes of d_records actually consumed
+ */
+int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats,
+                           uint32_t chk, void *d_out, uint64_t *consumed);
+
+/* apply_mask alone on device (the erasebytes restatement used by the GPU-side verification tools,
+ * src/tool/erasebytes.c:109-134): words [256, nwords) of a file &= mask(bits).  In place. */
+int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, uint64_t first_word_index, int bits);
+
+/* When on, every kernel launch is bracketed by HIP events on the context's stream (adds a host
+ * synchronisation per launch: use for profiling, not for throughput runs). */
+int mrcz_set_timing(mrcz_ctx_t *ctx, int on);
+
+/* per-kernel elapsed milliseconds of the last compress / uncompress call (HIP events on the
+ * context's stream); names are returned through `names` (static strings).  Returns count. */
+int mrcz_last_timings(const mrcz_ctx_t *ctx, const char **names, float *ms, int max);
+
+/* Inspection (tests): copy the block table of the last compressed batch to the host.
+ * For stream s (= 4*chunk + plane) fills up to max_blocks entries; returns number of blocks. */
+typedef struct {
+    uint32_t start, end;  /* byte span of the block in the plane */
+    uint32_t btype;       /* 0 stored, 1 static, 2 dynamic */
+    uint32_t opt_len, static_len;
+    uint32_t bitpos;      /* first bit of the block inside the plane's deflate stream */
+} mrcz_block_info_t;
+int mrcz_debug_blocks(mrcz_ctx_t *ctx, uint32_t stream, mrcz_block_info_t *blocks, uint32_t max_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRCZ_HIP_H_ */
