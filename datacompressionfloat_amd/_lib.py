@@ -1,0 +1,49 @@
+"""ctypes binding of the C ABI declared in include/mrcz_hip.h (no torch types cross it)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmrcz_hip.so")
+
+
+class MrczLibraryMissing(ImportError):
+    pass
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise MrczLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the codec."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    lib.mrcz_create.restype = i32
+    lib.mrcz_create.argtypes = [ctypes.POINTER(vp), i32, u32]
+    lib.mrcz_destroy.restype = None
+    lib.mrcz_destroy.argtypes = [vp]
+    lib.mrcz_last_error.restype = ctypes.c_char_p
+    lib.mrcz_last_error.argtypes = [vp]
+    lib.mrcz_stream.restype = vp
+    lib.mrcz_stream.argtypes = [vp]
+    lib.mrcz_records_bound.restype = u64
+    lib.mrcz_records_bound.argtypes = [u64]
+    lib.mrcz_compress_chunks.restype = i32
+    lib.mrcz_compress_chunks.argtypes = [vp, vp, u64, u64, i32, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    lib.mrcz_uncompress_chunks.restype = i32
+    lib.mrcz_uncompress_chunks.argtypes = [vp, vp, u64, u64, u32, vp, ctypes.POINTER(u64)]
+    lib.mrcz_erase_bits.restype = i32
+    lib.mrcz_erase_bits.argtypes = [vp, vp, u64, u64, i32]
+    lib.mrcz_set_timing.restype = i32
+    lib.mrcz_set_timing.argtypes = [vp, i32]
+    lib.mrcz_last_timings.restype = i32
+    lib.mrcz_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), i32]
+    return lib
+
+
+# every symbol include/mrcz_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTS = [
+    "mrcz_create", "mrcz_destroy", "mrcz_last_error", "mrcz_stream", "mrcz_records_bound",
+    "mrcz_compress_chunks", "mrcz_uncompress_chunks", "mrcz_erase_bits", "mrcz_set_timing",
+    "mrcz_last_timings", "mrcz_debug_blocks",
+]

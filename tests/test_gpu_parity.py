@@ -1,0 +1,156 @@
+"""GPU parity tests (the tests proper): the HIP path, called through the C ABI, against the CPU
+oracle on seeded inputs, against the committed reference containers / hashes, and -- at sizes the
+oracle would take too long for -- through size-independent properties (round trip == erasebytes,
+header arithmetic).  Integer/byte work: everything is compared bit-exactly."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+G = json.load(open(os.path.join(util.GOLDEN, "golden.json")))
+
+
+@pytest.fixture(scope="module")
+def codec():
+    import torch
+    from datacompressionfloat_amd import MrcZipCodec
+    assert torch.cuda.is_available()
+    c = MrcZipCodec(0, max_batch_chunks=8)
+    yield c
+    c.close()
+
+
+def _roundtrip(codec, oracle, words, bits, check_oracle=True):
+    data = np.ascontiguousarray(words, dtype=np.uint32).tobytes()
+    z = codec.zip_bytes(data, bits)
+    if check_oracle:
+        ref = oracle.compress(data, bits)
+        assert len(z) == len(ref) and z == ref, (len(words), bits, len(z), len(ref))
+    back = codec.unzip_bytes(z)
+    assert back == util.erase_expected(np.frombuffer(data, np.uint32), bits).tobytes()
+    return z
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 255, 256, 257, 300, 4095, 4096, 4097, 32767, 32768, 32769, 65536, 100000])
+def test_ragged_sizes_all_planes(codec, oracle, n):
+    rng = np.random.default_rng(n)
+    w = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    for b in (0, 8, 16, 24, 32):
+        _roundtrip(codec, oracle, w, b)
+
+
+@pytest.mark.parametrize("bits", list(range(0, 33)))
+def test_all_33_mask_levels_roundtrip_equals_erasebytes(codec, oracle, bits):
+    # the reference's own test loop (script/run_full_test.sh:84-102) + container byte identity
+    _roundtrip(codec, oracle, util.gauss_words(300000, seed=11), bits)
+
+
+def test_survey_appendix_d_known_answers(codec):
+    for name in ("katA", "katB"):
+        data = util.kat_words(G["kat_inputs"][name]).tobytes()
+        for b, (size, h) in G["survey_appendix_d"][name].items():
+            z = codec.zip_bytes(data, int(b))
+            assert len(z) == size, (name, b, len(z))
+            assert util.sha256(z).startswith(h), (name, b)
+            back = codec.unzip_bytes(z)
+            assert util.sha256(back) == G["regenerated"][f"{name}_b{b}"]["decoded_sha256"]
+
+
+def test_committed_reference_containers(codec):
+    from golden.make_golden import small_cases
+    for name, (data, bits) in small_cases().items():
+        ref = open(os.path.join(util.GOLDEN, name + ".zip"), "rb").read()
+        assert codec.zip_bytes(data, bits) == ref, name
+        back = codec.unzip_bytes(ref)  # decode what the REFERENCE wrote
+        n = len(data) // 4 * 4
+        assert back == util.erase_expected(np.frombuffer(data[:n], np.uint32), bits).tobytes()
+
+
+def test_seeded_volumes_match_reference_hashes(codec):
+    gens = {"gauss_4Mi_b8": lambda: util.gauss_words(4 * 1048576, seed=1234),
+            "gauss_16Mi_b8": lambda: util.gauss_words(16 * 1048576, seed=1234),
+            "poisson_7Mi_b0": lambda: util.poisson_words(7 * 1048576, seed=7)}
+    for name, gen in gens.items():
+        meta = G["large"][name]
+        data = gen().tobytes()
+        assert util.sha256(data) == meta["input_sha256"], "numpy generator drifted"
+        z = codec.zip_bytes(data, meta["bits"])
+        assert (len(z), util.sha256(z)) == (meta["size"], meta["sha256"]), name
+        assert codec.unzip_bytes(z) == util.erase_expected(np.frombuffer(data, np.uint32), meta["bits"]).tobytes()
+
+
+def test_run_structures(codec, oracle):
+    lens = [1, 2, 3, 4, 5, 257, 258, 259, 260, 261, 262, 515, 516, 517, 518, 519, 520, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097]
+    _roundtrip(codec, oracle, util.runs_words(1000000, lens, 3, seed=5), 0)
+    _roundtrip(codec, oracle, util.runs_words(500000, [1, 1, 1, 2, 3, 300, 1000, 5000, 70000], 2, seed=6), 0)
+    _roundtrip(codec, oracle, np.zeros(6291456 + 5, np.uint32), 0)        # single-block planes, full chunk + 5 floats
+    _roundtrip(codec, oracle, np.full(3000000, 0x41200000, np.uint32), 7)
+
+
+def test_skewed_alphabets_force_length_overflow(codec, oracle):
+    # Fibonacci byte frequencies in plane 0 push Huffman depths past 15 bits (App. B.3 overflow repair)
+    fib = [1, 1]
+    while sum(fib) < 30000:
+        fib.append(fib[-1] + fib[-2])
+    rng = np.random.default_rng(3)
+    p0 = np.concatenate([np.full(f, i, np.uint32) for i, f in enumerate(fib)])
+    rng.shuffle(p0)
+    w = p0 | (rng.integers(0, 4, len(p0), dtype=np.uint64).astype(np.uint32) << 8)
+    _roundtrip(codec, oracle, np.tile(w, 5), 0)
+
+
+def test_chunk_boundaries(codec, oracle):
+    C = util.CHUNK
+    for n in (C - 1, C, C + 1, 2 * C + 12345):
+        w = util.poisson_words(n, seed=n & 0xffff)
+        _roundtrip(codec, oracle, w, 8)
+
+
+def test_empty_and_invalid(codec):
+    from datacompressionfloat_amd import MrczError
+    assert codec.zip_bytes(b"", 0) == b""
+    assert codec.zip_bytes(b"abc", 5) == b""      # workers.c:757
+    with pytest.raises(MrczError):
+        codec.zip_bytes(b"\0" * 4096, 33)
+    with pytest.raises(MrczError):
+        codec.zip_bytes(b"\0" * 4096, -1)
+    z = codec.zip_bytes(util.gauss_words(5000).tobytes(), 8)
+    with pytest.raises(MrczError):
+        codec.unzip_bytes(z[: len(z) // 2])       # truncated container is rejected, not read out of bounds
+    with pytest.raises(MrczError):
+        codec.unzip_bytes(z[:10])
+
+
+def test_header_and_accounting(codec):
+    data = util.gauss_words(70001).tobytes() + b"xyz"
+    z = codec.zip_bytes(data, 8)
+    fsz, chk, typ, zt = struct.unpack("<QIb", z[:13]) + (z[13:17],)
+    assert (fsz, chk, typ, zt) == (len(data), 6291456, 0, b"\0\0\0\0")   # common.c:137-148
+    assert len(codec.unzip_bytes(z)) == 4 * (len(data) // 4)               # trailing fsz%4 bytes dropped (workers.c:744,854)
+
+
+def test_one_gib_roundtrip_property(codec):
+    """BASELINE config 2 size: 1 GiB, b=8; too big for the oracle inside a test -> properties only."""
+    import torch
+    n = 268435456
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.empty(n, dtype=torch.float32, device="cuda").normal_(10.0, 3.0, generator=g)
+    words = x.view(torch.int32)
+    big = type(codec)(0, max_batch_chunks=43)
+    rec, planes = big.compress_device(words, 8, 0)
+    nchunks = (n + util.CHUNK - 1) // util.CHUNK
+    assert sum(planes) == rec.numel() + 0 * nchunks            # zfsz sums include the 4-byte plane headers = 16 B per chunk
+    out, consumed = big.uncompress_device(rec, n)
+    assert consumed == rec.numel()
+    exp = words.clone()
+    big.erase_bits_device(exp, 8, 0)
+    assert torch.equal(out, exp)
+    # plane 0 is all zero after masking 8 bits: ~6 KiB per chunk; plane 1 is incompressible -> RAW
+    assert rec.numel() < 0.6 * 4 * n
+    big.close()
