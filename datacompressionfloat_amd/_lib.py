@@ -38,6 +38,8 @@ def load():
     lib.mrcz_set_timing.argtypes = [vp, i32]
     lib.mrcz_last_timings.restype = i32
     lib.mrcz_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), i32]
+    lib.mrcz_debug_fallbacks.restype = ctypes.c_int64
+    lib.mrcz_debug_fallbacks.argtypes = [vp]
     return lib
 
 
@@ -45,5 +47,5 @@ def load():
 EXPORTS = [
     "mrcz_create", "mrcz_destroy", "mrcz_last_error", "mrcz_stream", "mrcz_records_bound",
     "mrcz_compress_chunks", "mrcz_uncompress_chunks", "mrcz_erase_bits", "mrcz_set_timing",
-    "mrcz_last_timings", "mrcz_debug_blocks",
+    "mrcz_last_timings", "mrcz_debug_blocks", "mrcz_debug_fallbacks",
 ]

@@ -71,6 +71,10 @@ class MrcZipCodec:
         n = _LIB.mrcz_last_timings(self._ctx, names, ms, 32)
         return {names[i].decode(): float(ms[i]) for i in range(n)}
 
+    def last_fallbacks(self) -> int:
+        """streams of the last uncompress call that needed the sequential general-distance decoder"""
+        return int(_LIB.mrcz_debug_fallbacks(self._ctx))
+
     @staticmethod
     def records_bound(nfloats: int) -> int:
         return int(_LIB.mrcz_records_bound(nfloats))

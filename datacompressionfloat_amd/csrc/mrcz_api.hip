@@ -10,6 +10,7 @@
 #include "mrcz_compress.hip"
 #include "mrcz_huffman.hip"
 #include "mrcz_inflate.hip"
+#include "mrcz_inflate_par.hip"
 
 #include "../../include/mrcz_hip.h"
 
@@ -44,6 +45,7 @@ struct mrcz_ctx {
     uint64_t *result;      /* device: [0] running byte offset, [1..4] plane sums / error */
     uint64_t *h_result;    /* pinned host mirror */
     DecStream *dstreams;
+    uint32_t *fallback;
     uint8_t *planes;       /* decode only, allocated lazily */
     /* timing */
     int timing;
@@ -53,6 +55,7 @@ struct mrcz_ctx {
     hipEvent_t ev0, ev1;
     /* inspection */
     uint32_t last_streams;
+    uint64_t last_fallbacks;
 };
 
 static int fail(mrcz_ctx *c, int code, const char *what, hipError_t e)
@@ -102,6 +105,7 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->blkbase, ns + 1);
     if (e == hipSuccess) e = dalloc(&ctx->result, 8);
     if (e == hipSuccess) e = dalloc(&ctx->dstreams, ns);
+    if (e == hipSuccess) e = dalloc(&ctx->fallback, ns);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
@@ -121,7 +125,7 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     (void)hipFree(ctx->tsum); (void)hipFree(ctx->tinfo); (void)hipFree(ctx->sinfo); (void)hipFree(ctx->blkstart);
     (void)hipFree(ctx->slideq); (void)hipFree(ctx->pairhist); (void)hipFree(ctx->blkfreq); (void)hipFree(ctx->blkcode);
     (void)hipFree(ctx->blkhdr); (void)hipFree(ctx->meta); (void)hipFree(ctx->lay); (void)hipFree(ctx->pairbits);
-    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams);
+    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback);
     (void)hipFree(ctx->planes);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -242,7 +246,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
     if (nfloats == 0) return MRCZ_OK;
     if (!d_records) return MRCZ_EINVAL;
     if (chk == 0 || chk > CHK) return fail(ctx, MRCZ_EFORMAT, "chunk size in header exceeds CHUNK_SIZE (constant.h:25)", hipSuccess);
-    if ((uintptr_t)d_out & 15u) return fail(ctx, MRCZ_EINVAL, "d_out must be 16-byte aligned", hipSuccess);
+    if (((uintptr_t)d_out & 15u) || ((uintptr_t)d_records & 3u)) return fail(ctx, MRCZ_EINVAL, "d_out must be 16-byte and d_records 4-byte aligned", hipSuccess);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     if (!ctx->planes) {
         hipError_t e = hipMalloc((void **)&ctx->planes, (size_t)4 * ctx->max_chunks * CHK);
@@ -256,12 +260,14 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
         const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
         const uint64_t bfl = (nfloats - c0 * chk) < (uint64_t)nb * chk ? (nfloats - c0 * chk) : (uint64_t)nb * chk;
         LAUNCH("k_parse_records", k_parse_records, dim3(1), dim3(64), rec, len, bfl, chk, ctx->dstreams, ctx->result);
-        LAUNCH("k_inflate", k_inflate, dim3(4 * nb), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result);
+        LAUNCH("k_inflate_par", k_inflate_par, dim3(4 * nb), dim3(PT), rec, len, ctx->dstreams, ctx->planes, ctx->fallback);
+        LAUNCH("k_inflate_seq", k_inflate, dim3(4 * nb), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
         LAUNCH("k_merge_planes", k_merge_planes, dim3(1024, nb), dim3(256), ctx->planes, bfl, chk, out + c0 * chk);
     }
     HIPCHK(hipMemcpyAsync(ctx->h_result, ctx->result, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (uncompress)");
     if (consumed) *consumed = ctx->h_result[0];
+    ctx->last_fallbacks = ctx->h_result[2];
     if (ctx->h_result[1]) return fail(ctx, MRCZ_EFORMAT, "malformed chunk records or deflate stream", hipSuccess);
     return MRCZ_OK;
 }
@@ -277,6 +283,8 @@ extern "C" int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, 
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (erase)");
     return MRCZ_OK;
 }
+
+extern "C" int64_t mrcz_debug_fallbacks(const mrcz_ctx_t *ctx) { return ctx ? (int64_t)ctx->last_fallbacks : -1; }
 
 extern "C" int mrcz_debug_blocks(mrcz_ctx_t *ctx, uint32_t stream, mrcz_block_info_t *blocks, uint32_t max_blocks)
 {

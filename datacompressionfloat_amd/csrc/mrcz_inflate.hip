@@ -8,9 +8,9 @@
  * streams are decoded concurrently, one wave per stream.
  *
  *   k_parse_records  walks the 16-byte chunk headers (unpack_header, zip.c:393-399)
- *   k_inflate        v1: lane 0 of each wave decodes its stream sequentially (general DEFLATE:
- *                    stored / fixed / dynamic blocks, any distance), RAW planes are copied by the
- *                    whole wave
+ *   k_inflate_par    (mrcz_inflate_par.hip) 1024 threads per stream, self-synchronising parallel decode
+ *   k_inflate        sequential general decoder (any distance); only runs for streams the parallel
+ *                    kernel hands over (matches with distance != 1, or malformed input)
  *   k_merge_planes   4 byte planes -> float words (uint4 stores)
  */
 #include "mrcz_common.h"
@@ -142,11 +142,13 @@ __device__ __forceinline__ int decode_sym(BitReader &r, const DecTable &t)
 }
 
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ rec, const DecStream *__restrict__ ds,
-                                                uint8_t *__restrict__ planes, uint64_t *__restrict__ result)
+                                                uint8_t *__restrict__ planes, uint64_t *__restrict__ result,
+                                                const uint32_t *__restrict__ only /* NULL, or per-stream flag: decode iff != 0 */)
 {
     __shared__ DecTable tl, td;
     __shared__ uint8_t lens[320];
     const uint32_t s = blockIdx.x;
+    if (only && only[s] == 0) return;
     const DecStream d = ds[s];
     uint8_t *out = planes + (size_t)s * CHK;
     const int lane = lane_id();
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ rec,
         return;
     }
     if (lane != 0) return;
+    if (only) atomicAdd((unsigned long long *)&result[2], 1ull); /* streams the parallel decoder handed over */
     const uint16_t base_len[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     const uint16_t base_dist[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};

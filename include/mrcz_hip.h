@@ -108,6 +108,11 @@ typedef struct {
 } mrcz_block_info_t;
 int mrcz_debug_blocks(mrcz_ctx_t *ctx, uint32_t stream, mrcz_block_info_t *blocks, uint32_t max_blocks);
 
+/* Inspection (tests): number of streams of the last mrcz_uncompress_chunks call that the parallel
+ * decoder handed to the sequential general-distance decoder (0 for streams this codec or zlib
+ * Z_RLE wrote). */
+int64_t mrcz_debug_fallbacks(const mrcz_ctx_t *ctx);
+
 #ifdef __cplusplus
 }
 #endif

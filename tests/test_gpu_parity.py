@@ -34,6 +34,7 @@ def _roundtrip(codec, oracle, words, bits, check_oracle=True):
         assert len(z) == len(ref) and z == ref, (len(words), bits, len(z), len(ref))
     back = codec.unzip_bytes(z)
     assert back == util.erase_expected(np.frombuffer(data, np.uint32), bits).tobytes()
+    assert codec.last_fallbacks() == 0  # decoded by the parallel kernel, not the sequential one
     return z
 
 
@@ -145,9 +146,9 @@ def test_one_gib_roundtrip_property(codec):
     big = type(codec)(0, max_batch_chunks=43)
     rec, planes = big.compress_device(words, 8, 0)
     nchunks = (n + util.CHUNK - 1) // util.CHUNK
-    assert sum(planes) == rec.numel() + 0 * nchunks            # zfsz sums include the 4-byte plane headers = 16 B per chunk
+    assert sum(planes) == rec.numel()                          # zfsz sums include the 4-byte plane headers = 16 B per chunk
     out, consumed = big.uncompress_device(rec, n)
-    assert consumed == rec.numel()
+    assert consumed == rec.numel() and big.last_fallbacks() == 0
     exp = words.clone()
     big.erase_bits_device(exp, 8, 0)
     assert torch.equal(out, exp)

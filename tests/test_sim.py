@@ -16,6 +16,7 @@ def _check(sim, oracle, words, bits):
     assert got == ref, (len(words), bits, len(got), len(ref))
     dec = sim.uncompress_records(ref, len(words))
     assert np.array_equal(dec, util.erase_expected(words, bits))
+    assert sim.fallbacks == 0  # the parallel decoder handled every stream itself
 
 
 @pytest.mark.parametrize("n", [1, 3, 255, 256, 257, 4095, 4096, 4097, 10000])

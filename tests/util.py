@@ -173,6 +173,8 @@ class SimCodec:
         lib.mrcz_uncompress_chunks.argtypes = [vp, vp, u64, u64, u32, vp, ctypes.POINTER(u64)]
         lib.mrcz_last_error.restype = ctypes.c_char_p
         lib.mrcz_last_error.argtypes = [vp]
+        lib.mrcz_debug_fallbacks.restype = ctypes.c_int64
+        lib.mrcz_debug_fallbacks.argtypes = [vp]
         self.ctx = vp()
         assert lib.mrcz_create(ctypes.byref(self.ctx), 0, max_batch_chunks) == 0
 
@@ -196,6 +198,7 @@ class SimCodec:
         rc = self.lib.mrcz_uncompress_chunks(self.ctx, r.ctypes.data, len(rec), nfloats, chk, out.ctypes.data, ctypes.byref(cons))
         if rc != 0:
             raise RuntimeError(f"sim uncompress rc={rc}: {self.lib.mrcz_last_error(self.ctx)}")
+        self.fallbacks = int(self.lib.mrcz_debug_fallbacks(self.ctx))
         return out.copy()
 
 
