@@ -47,5 +47,5 @@ def load():
 EXPORTS = [
     "mrcz_create", "mrcz_destroy", "mrcz_last_error", "mrcz_stream", "mrcz_records_bound",
     "mrcz_compress_chunks", "mrcz_uncompress_chunks", "mrcz_erase_bits", "mrcz_set_timing",
-    "mrcz_last_timings", "mrcz_debug_blocks", "mrcz_debug_fallbacks",
+    "mrcz_last_timings", "mrcz_debug_blocks", "mrcz_debug_fallbacks", "mrcz_debug_inflate_phases",
 ]

@@ -46,6 +46,8 @@ struct mrcz_ctx {
     uint64_t *h_result;    /* pinned host mirror */
     DecStream *dstreams;
     uint32_t *fallback;
+    unsigned long long *dbgphase; /* 8 counters per stream when phase profiling is on */
+    int phase_profile;
     uint8_t *planes;       /* decode only, allocated lazily */
     /* timing */
     int timing;
@@ -69,6 +71,8 @@ static int fail(mrcz_ctx *c, int code, const char *what, hipError_t e)
         hipError_t e_ = (call);                                   \
         if (e_ != hipSuccess) return fail(ctx, MRCZ_EHIP, what, e_); \
     } while (0)
+
+static size_t inflate_par_lds() { return ((sizeof(ParShared) + 15u) & ~(size_t)15u) + STG_BYTES + 64u; }
 
 template <typename T> static hipError_t dalloc(T **p, size_t count) { return hipMalloc((void **)p, count * sizeof(T)); }
 
@@ -106,9 +110,12 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->result, 8);
     if (e == hipSuccess) e = dalloc(&ctx->dstreams, ns);
     if (e == hipSuccess) e = dalloc(&ctx->fallback, ns);
+    if (e == hipSuccess) e = dalloc(&ctx->dbgphase, ns * 20);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    /* the parallel inflate keeps its window, tables and a 32 KiB output stage in LDS (> 64 KiB) */
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_inflate_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
     if (e != hipSuccess) {
         mrcz_destroy(ctx);
         return e == hipSuccess ? MRCZ_ENOMEM : MRCZ_ENOMEM;
@@ -125,7 +132,7 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     (void)hipFree(ctx->tsum); (void)hipFree(ctx->tinfo); (void)hipFree(ctx->sinfo); (void)hipFree(ctx->blkstart);
     (void)hipFree(ctx->slideq); (void)hipFree(ctx->pairhist); (void)hipFree(ctx->blkfreq); (void)hipFree(ctx->blkcode);
     (void)hipFree(ctx->blkhdr); (void)hipFree(ctx->meta); (void)hipFree(ctx->lay); (void)hipFree(ctx->pairbits);
-    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback);
+    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->dbgphase);
     (void)hipFree(ctx->planes);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -154,6 +161,21 @@ extern "C" uint64_t mrcz_records_bound(uint64_t nfloats)
     do {                                                                                    \
         if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);                       \
         hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, __VA_ARGS__);               \
+        if (ctx->timing) {                                                                  \
+            (void)hipEventRecord(ctx->ev1, ctx->stream);                                    \
+            (void)hipEventSynchronize(ctx->ev1);                                            \
+            float ms_ = 0.f;                                                                \
+            (void)hipEventElapsedTime(&ms_, ctx->ev0, ctx->ev1);                            \
+            timer_add(ctx, name, ms_);                                                      \
+        }                                                                                   \
+        HIPCHK(hipGetLastError(), name);                                                    \
+    } while (0)
+
+/* same, with dynamic LDS */
+#define LAUNCH_S(name, kernel, grid, block, shmem, ...)                                     \
+    do {                                                                                    \
+        if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);                       \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, __VA_ARGS__);           \
         if (ctx->timing) {                                                                  \
             (void)hipEventRecord(ctx->ev1, ctx->stream);                                    \
             (void)hipEventSynchronize(ctx->ev1);                                            \
@@ -260,7 +282,8 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
         const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
         const uint64_t bfl = (nfloats - c0 * chk) < (uint64_t)nb * chk ? (nfloats - c0 * chk) : (uint64_t)nb * chk;
         LAUNCH("k_parse_records", k_parse_records, dim3(1), dim3(64), rec, len, bfl, chk, ctx->dstreams, ctx->result);
-        LAUNCH("k_inflate_par", k_inflate_par, dim3(4 * nb), dim3(PT), rec, len, ctx->dstreams, ctx->planes, ctx->fallback);
+        LAUNCH_S("k_inflate_par", k_inflate_par, dim3(4 * nb), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
+               ctx->phase_profile ? ctx->dbgphase : (unsigned long long *)NULL);
         LAUNCH("k_inflate_seq", k_inflate, dim3(4 * nb), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
         LAUNCH("k_merge_planes", k_merge_planes, dim3(1024, nb), dim3(256), ctx->planes, bfl, chk, out + c0 * chk);
     }
@@ -281,6 +304,17 @@ extern "C" int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, 
     ctx->ntimers = 0;
     LAUNCH("k_erase_bits", k_erase_bits, dim3(2048), dim3(256), (uint32_t *)d_words, nwords, first_word_index, mask_of(bits));
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (erase)");
+    return MRCZ_OK;
+}
+
+extern "C" int mrcz_debug_inflate_phases(mrcz_ctx_t *ctx, int enable, uint32_t stream, uint64_t out[20])
+{
+    if (!ctx) return MRCZ_EINVAL;
+    ctx->phase_profile = enable;
+    if (out) {
+        if (stream >= 4u * ctx->max_chunks) return MRCZ_EINVAL;
+        if (hipMemcpy(out, ctx->dbgphase + (size_t)stream * 20, 20 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return MRCZ_EHIP;
+    }
     return MRCZ_OK;
 }
 

@@ -32,12 +32,14 @@ constexpr int MAXTOK = 24;                    /* longest token (bits) the parall
 constexpr uint32_t X_ERR = 30u, X_EOB = 31u;
 constexpr int WIN_WORDS = WINBITS / 32 + 8;   /* + alignment lead + lookahead */
 constexpr int HDR_WORDS = 192;                /* staged bits for a dynamic header */
-constexpr int LBITS = 10;
+constexpr int LBITS = 12;                     /* index bits of the literal/length fast tables */
+constexpr int DBITS = 10;                     /* index bits of the distance fast table */
 constexpr uint32_t POS_INVALID = 0xffffffffu;
 enum { F_EOB = 1, F_ERR = 2, F_GENERAL = 4 };
 
 struct HuffDec {
-    uint16_t lut[1 << LBITS]; /* sym | len << 9; 0 = code longer than LBITS (or unused) */
+    uint16_t lut[1 << LBITS]; /* sym | len << 9; 0 = code longer than the table's index bits (or unused) */
+    uint16_t limit[16];       /* left-justified (15-bit) upper bound of the codes of each length */
     uint16_t count[16];
     uint16_t first[16];
     uint16_t offs[16];
@@ -51,7 +53,10 @@ struct ParShared {
     uint32_t scan_a[PT / 64];
     uint32_t scan_b[PT / 64];
     HuffDec lit, dist;
+    uint32_t bitmap[PT];      /* literal positions of the staged output segment */
     uint16_t bllut[128];      /* code-length code (<= 7 bits): sym | len << 9 */
+    uint8_t tb[1 << LBITS];   /* token bits when the 12 index bits determine them, 0 = take the general path */
+    uint16_t tn[1 << LBITS];  /* plane bytes that token produces (1 literal, 3..258 match); 0xffff = not distance 1 */
     uint8_t bl[32];           /* code-length code lengths */
     uint32_t ncode, hpos;
     uint8_t lens[320];
@@ -61,6 +66,7 @@ struct ParShared {
     uint32_t status;    /* 0 running, 1 done, 2 error, 3 needs the sequential decoder */
     uint32_t btype, bfinal, nlen, ndist;
     uint32_t flag;
+    unsigned long long acc[20], tp; /* phase counters (profiling builds of the call only) */
     uint32_t dmax;      /* longest distance code + extra bits of the current block */
     uint32_t maxtok;    /* longest token of the current block, bits (<= MAXTOK on the parallel path) */
 };
@@ -109,6 +115,9 @@ __device__ __forceinline__ void huff_build(HuffDec &h, const uint8_t *lens, int 
             const uint32_t c = h.count[len];
             h.first[len] = (uint16_t)code;
             h.offs[len] = (uint16_t)idx;
+            /* codes of this length, left-justified to 15 bits, are < limit[len] (non-decreasing in len) */
+            const uint32_t lim = (code + c) << (15 - len);
+            h.limit[len] = (uint16_t)(lim > 0x7fffu ? 0x8000u : lim);
             code = (code + c) << 1;
             idx += c;
         }
@@ -119,25 +128,43 @@ __device__ __forceinline__ void huff_build(HuffDec &h, const uint8_t *lens, int 
         for (int ww = 0; ww < w; ww++) base += h.wcnt[ww][mylen];
         const uint32_t r = base + (uint32_t)rank;
         h.sorted[h.offs[mylen] + r] = (uint16_t)tid;
-        if (mylen <= lutbits) {
-            const uint32_t rev = __brev((uint32_t)h.first[mylen] + r) >> (32 - mylen);
-            for (uint32_t j = rev; j < (1u << lutbits); j += (1u << mylen)) lut[j] = (uint16_t)(tid | (mylen << 9));
+    }
+    __syncthreads();
+    /* fast table, filled entry by entry (a short code covers thousands of entries: never let one
+     * thread loop over them): the entry's bit-reversed index, compared against the per-length
+     * limits, gives the code length; every entry is written, so no zeroing pass is needed */
+    for (uint32_t idx = (uint32_t)tid; idx < (1u << lutbits); idx += PT) {
+        const uint32_t x = (__brev(idx) >> (32 - lutbits)) << (15 - lutbits); /* left-justified 15-bit prefix */
+        int len = 0;
+        for (int k = lutbits; k >= 1; k--) if (x < h.limit[k]) len = k; /* smallest k with x < limit[k] */
+        uint32_t e = 0;
+        if (len) {
+            const uint32_t d = (x >> (15 - len)) - h.first[len];
+            if (d < h.count[len]) e = (uint32_t)h.sorted[h.offs[len] + d] | ((uint32_t)len << 9);
         }
+        lut[idx] = (uint16_t)e;
     }
     __syncthreads();
 }
-/* decode one symbol from the low bits of v (>= 15 valid bits); returns sym | len << 16, or 0xffffffff */
-__device__ __forceinline__ uint32_t huff_decode(const HuffDec &h, uint32_t v)
+/* decode one symbol from the low bits of v (>= 15 valid bits); returns sym | len << 16, or 0xffffffff.
+ * Codes longer than the table's index bits are resolved by comparing the left-justified 15-bit
+ * prefix against the per-length limits (canonical codes are ordered by length), not by a bit loop. */
+template <int TBITS>
+__device__ __forceinline__ uint32_t huff_decode_t(const HuffDec &h, uint32_t v)
 {
-    const uint32_t e = h.lut[v & ((1u << LBITS) - 1u)];
+    const uint32_t e = h.lut[v & ((1u << TBITS) - 1u)];
     if (e) return (e & 511u) | ((e >> 9) << 16);
-    for (int l = LBITS + 1; l <= 15; l++) {
-        const uint32_t code = __brev(v & ((1u << l) - 1u)) >> (32 - l);
-        const uint32_t d = code - h.first[l];
-        if (d < h.count[l]) return (uint32_t)h.sorted[h.offs[l] + d] | ((uint32_t)l << 16);
-    }
-    return 0xffffffffu;
+    const uint32_t x = __brev(v) >> 17; /* first 15 stream bits, MSB first */
+    int l = TBITS + 1;
+#pragma unroll
+    for (int k = TBITS + 1; k < 15; k++) l += (x >= h.limit[k]) ? 1 : 0;
+    if (x >= h.limit[15]) return 0xffffffffu;
+    const uint32_t d = (x >> (15 - l)) - h.first[l];
+    if (d >= h.count[l]) return 0xffffffffu;
+    return (uint32_t)h.sorted[h.offs[l] + d] | ((uint32_t)l << 16);
 }
+__device__ __forceinline__ uint32_t huff_decode(const HuffDec &h, uint32_t v) { return huff_decode_t<LBITS>(h, v); }
+__device__ __forceinline__ uint32_t huff_decode_dist(const HuffDec &h, uint32_t v) { return huff_decode_t<DBITS>(h, v); }
 
 __device__ __forceinline__ uint32_t base_len_of(int lc) /* lc 0..28 -> match length base */
 {
@@ -171,37 +198,75 @@ __device__ __forceinline__ ExitFn fn_identity()
     for (uint32_t e = 0; e < 12; e++) { f.lo |= (unsigned long long)e << (5 * e); f.hi |= (unsigned long long)(e + 12) << (5 * e); }
     return f;
 }
-/* result[e] = second[first[e]]; 30/31 are absorbing */
-__device__ __forceinline__ ExitFn fn_compose(const ExitFn &first, const ExitFn &second, uint32_t maxtok)
+/* result[e] = second[first[e]]; 30/31 are absorbing.  Fully unrolled: the entry index is static,
+ * only the lookup into `second` is a dynamic bit-field extract. */
+__device__ __forceinline__ ExitFn fn_compose(const ExitFn &first, const ExitFn &second)
 {
     ExitFn r;
     r.lo = 0; r.hi = 0;
-    for (uint32_t e = 0; e < maxtok; e++) {
-        const uint32_t v = fn_get(first, e);
-        const unsigned long long o = v >= (uint32_t)MAXTOK ? v : fn_get(second, v);
-        if (e < 12u) r.lo |= o << (5u * e); else r.hi |= o << (5u * (e - 12u));
+#pragma unroll
+    for (int e = 0; e < 12; e++) {
+        const uint32_t v = (uint32_t)(first.lo >> (5 * e)) & 31u;
+        const unsigned long long w = v < 12u ? second.lo : second.hi;
+        const unsigned long long o = v >= (uint32_t)MAXTOK ? (unsigned long long)v : ((w >> (5u * (v < 12u ? v : v - 12u))) & 31ull);
+        r.lo |= o << (5 * e);
+    }
+#pragma unroll
+    for (int e = 0; e < 12; e++) {
+        const uint32_t v = (uint32_t)(first.hi >> (5 * e)) & 31u;
+        const unsigned long long w = v < 12u ? second.lo : second.hi;
+        const unsigned long long o = v >= (uint32_t)MAXTOK ? (unsigned long long)v : ((w >> (5u * (v < 12u ? v : v - 12u))) & 31ull);
+        r.hi |= o << (5 * e);
     }
     return r;
 }
 
-/* total bits of the token that starts at the low bit of v (>= 33 valid bits); X_EOB/X_ERR << 8 for specials */
+/* total bits of the token that starts at the low bit of v (>= 33 valid bits): 1..MAXTOK, or
+ * X_EOB (END_BLOCK) / X_ERR (invalid, or a token the parallel path does not resolve) */
 __device__ __forceinline__ uint32_t token_bits(const ParShared &sh, unsigned long long v)
 {
     const uint32_t d = huff_decode(sh.lit, (uint32_t)v);
-    if (d == 0xffffffffu) return X_ERR << 8;
+    if (d == 0xffffffffu) return X_ERR;
     const uint32_t l = d >> 16, sym = d & 0xffffu;
     if (sym < 256u) return l;
-    if (sym == 256u) return X_EOB << 8;
+    if (sym == 256u) return X_EOB;
     const int lc = (int)sym - 257;
-    if (lc >= 29) return X_ERR << 8;
+    if (lc >= 29) return X_ERR;
     const uint32_t xb = (uint32_t)len_extra_bits(lc);
-    const uint32_t de = sh.dist.lut[(uint32_t)(v >> (l + xb)) & ((1u << LBITS) - 1u)];
-    if (!de) return X_ERR << 8; /* distance code longer than the fast table: sequential decoder */
+    const uint32_t de = sh.dist.lut[(uint32_t)(v >> (l + xb)) & ((1u << DBITS) - 1u)];
+    if (!de) return X_ERR; /* distance code longer than the fast table: sequential decoder */
     const uint32_t dc = de & 511u, dl = de >> 9;
-    if (dc >= 30u) return X_ERR << 8;
+    if (dc >= 30u) return X_ERR;
     const uint32_t dxb = dc < 4u ? 0u : (dc >> 1) - 1u;
     const uint32_t t = l + xb + dl + dxb;
-    return t > (uint32_t)MAXTOK ? (X_ERR << 8) : t;
+    return t > (uint32_t)MAXTOK ? X_ERR : t;
+}
+
+/* entry of the fast token table for the 10-bit pattern idx: the token's total bits when they are
+ * fully determined by those 10 bits (literal / END_BLOCK code <= 10 bits, or a match whose length
+ * code + extra bits + distance CODE fit in 10 bits), else 0 = ask token_bits() */
+__device__ __forceinline__ uint32_t fast_token_entry(const ParShared &sh, uint32_t idx, uint32_t *nbytes)
+{
+    *nbytes = 0;
+    const uint32_t e = sh.lit.lut[idx];
+    if (!e) return 0;
+    const uint32_t l = e >> 9, sym = e & 511u;
+    if (sym < 256u) { *nbytes = 1; return l; }
+    if (sym == 256u) return X_EOB;
+    const int lc = (int)sym - 257;
+    if (lc >= 29) return X_ERR;
+    const uint32_t xb = (uint32_t)len_extra_bits(lc);
+    if (l + xb >= (uint32_t)LBITS) return 0;
+    const uint32_t avail = (uint32_t)LBITS - l - xb;
+    const uint32_t de = sh.dist.lut[(idx >> (l + xb)) & ((1u << DBITS) - 1u)];
+    if (!de) return 0;
+    const uint32_t dc = de & 511u, dl = de >> 9;
+    if (dl > avail) return 0;
+    if (dc >= 30u) return X_ERR;
+    const uint32_t dxb = dc < 4u ? 0u : (dc >> 1) - 1u;
+    const uint32_t t = l + xb + dl + dxb;
+    *nbytes = dc == 0u ? base_len_of(lc) + ((idx >> l) & ((1u << xb) - 1u)) : 0xffffu;
+    return t > (uint32_t)MAXTOK ? X_ERR : t;
 }
 
 /* P1: exit function of the piece [s, s + SUBBITS) of the staged window.  Positions are handled
@@ -215,19 +280,29 @@ __device__ __forceinline__ ExitFn piece_exit_fn(const ParShared &sh, uint32_t s)
         const uint32_t wi = p0 >> 5, b0 = p0 & 31u;
         const unsigned long long w01 = (unsigned long long)sh.win[wi] | ((unsigned long long)sh.win[wi + 1] << 32);
         const unsigned long long w12 = (w01 >> 32) | ((unsigned long long)sh.win[wi + 2] << 32);
-        uint32_t t[8];
+        unsigned long long T = 0; /* 8 token codes, one byte each */
+        uint32_t slow = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t b = b0 + (uint32_t)j;
             const unsigned long long v = b < 32u ? (w01 >> b) : (w12 >> (b - 32u));
-            t[j] = token_bits(sh, v);
+            const uint32_t tj = sh.tb[(uint32_t)v & ((1u << LBITS) - 1u)];
+            T |= (unsigned long long)tj << (8 * j);
+            slow |= (tj == 0u ? 1u : 0u) << j;
+        }
+        while (slow) { /* tokens the 10-bit table cannot size: one general decode per iteration */
+            const uint32_t j = (uint32_t)__builtin_ctz(slow);
+            slow &= slow - 1u;
+            const uint32_t b = b0 + j;
+            const uint32_t tj = token_bits(sh, b < 32u ? (w01 >> b) : (w12 >> (b - 32u)));
+            T |= (unsigned long long)tj << (8u * j);
         }
 #pragma unroll
         for (int j = 7; j >= 0; j--) {
             const uint32_t k = 8u * (uint32_t)g + (uint32_t)j;
-            const uint32_t tt = t[j];
+            const uint32_t tt = (uint32_t)(T >> (8 * j)) & 255u;
             unsigned long long ex;
-            if (tt >> 8) ex = tt >> 8;
+            if (tt >= X_ERR) ex = tt;
             else if (k + tt >= (uint32_t)SUBBITS) ex = k + tt - (uint32_t)SUBBITS;
             else {
                 const uint32_t e = tt - 1u;
@@ -260,9 +335,10 @@ struct SubResult {
     uint32_t lastlit; /* 0x100 | byte if the lane decoded a literal, else 0 */
 };
 
-/* decode symbols from window bit `start` until the position reaches `limit` (or END_BLOCK) */
-template <bool WRITE>
-__device__ __forceinline__ SubResult decode_sub(const ParShared &sh, uint32_t start, uint32_t limit, uint8_t *out, uint32_t inbyte)
+/* P3: count walk.  Decode tokens from window bit `start` until the position reaches `limit` (or
+ * END_BLOCK), counting the plane bytes they produce.  Nearly every token is sized by the two fast
+ * tables (token bits, produced bytes) with a single 12-bit lookup each. */
+__device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t start, uint32_t limit)
 {
     SubResult r;
     r.nout = 0; r.flags = 0; r.lastlit = 0;
@@ -271,18 +347,23 @@ __device__ __forceinline__ SubResult decode_sub(const ParShared &sh, uint32_t st
     uint64_t buf = ((uint64_t)sh.win[wi] | ((uint64_t)sh.win[wi + 1] << 32)) >> (pos & 31u);
     int nb = 64 - (int)(pos & 31u);
     wi += 2;
-    uint32_t last = inbyte;
     while (pos < limit) {
         if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
+        const uint32_t idx = (uint32_t)buf & ((1u << LBITS) - 1u);
+        const uint32_t t = sh.tb[idx];
+        const uint32_t n = sh.tn[idx];
+        if (t - 1u < (uint32_t)MAXTOK && n != 0xffffu) { /* 1 <= t <= MAXTOK, distance 1 */
+            buf >>= t; nb -= (int)t; pos += t;
+            r.nout += n;
+            continue;
+        }
+        /* general path: long codes, END_BLOCK, other distances, errors */
         const uint32_t d = huff_decode(sh.lit, (uint32_t)buf);
         if (d == 0xffffffffu) { r.flags |= F_ERR; break; }
         const int l = (int)(d >> 16);
         const uint32_t sym = d & 0xffffu;
         buf >>= l; nb -= l; pos += (uint32_t)l;
         if (sym < 256u) {
-            if (WRITE) out[r.nout] = (uint8_t)sym;
-            last = sym;
-            r.lastlit = 0x100u | sym;
             r.nout++;
         } else if (sym == 256u) {
             r.flags |= F_EOB;
@@ -294,7 +375,7 @@ __device__ __forceinline__ SubResult decode_sub(const ParShared &sh, uint32_t st
             const uint32_t ml = base_len_of(lc) + ((uint32_t)buf & ((1u << xb) - 1u));
             buf >>= xb; nb -= xb; pos += (uint32_t)xb;
             if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
-            const uint32_t dd = huff_decode(sh.dist, (uint32_t)buf);
+            const uint32_t dd = huff_decode_dist(sh.dist, (uint32_t)buf);
             if (dd == 0xffffffffu || (dd & 0xffffu) >= 30u) { r.flags |= F_ERR; break; }
             const int dl = (int)(dd >> 16), dc = (int)(dd & 0xffffu);
             buf >>= dl; nb -= dl; pos += (uint32_t)dl;
@@ -302,13 +383,81 @@ __device__ __forceinline__ SubResult decode_sub(const ParShared &sh, uint32_t st
             const uint32_t dist = base_dist_of(dc) + ((uint32_t)buf & ((1u << dxb) - 1u));
             buf >>= dxb; nb -= dxb; pos += (uint32_t)dxb;
             if (dist != 1u) r.flags |= F_GENERAL;
-            if (WRITE) for (uint32_t k = 0; k < ml; k++) out[r.nout + k] = (uint8_t)last;
             r.nout += ml;
         }
     }
     r.land = pos;
     return r;
 }
+
+/* P4: resumable write walk.  Plane bytes are staged in LDS (segment [seg_lo, seg_hi) of the window's
+ * output) and flushed to HBM with coalesced 16-byte stores by the whole workgroup: per-lane byte or
+ * dword stores scatter over 64 cache lines per wave instruction and were the slowest phase. */
+struct Walker {
+    uint64_t buf;
+    uint32_t pos, limit, wi;
+    int nb;
+    uint32_t off;    /* window-relative output offset of the next byte */
+    uint32_t done;
+};
+__device__ __forceinline__ void walker_init(Walker &w, const ParShared &sh, uint32_t start, uint32_t limit, uint32_t off)
+{
+    w.pos = start; w.limit = limit; w.off = off; w.done = 0;
+    w.wi = start >> 5;
+    w.buf = ((uint64_t)sh.win[w.wi] | ((uint64_t)sh.win[w.wi + 1] << 32)) >> (start & 31u);
+    w.nb = 64 - (int)(start & 31u);
+    w.wi += 2;
+}
+/* distance-1 matches replicate the previous byte, so the plane is fully defined by its literals:
+ * lanes only scatter literal bytes (and mark them in a bitmap); a uniform forward fill then expands
+ * the runs without any per-lane variable-length loop. */
+__device__ __forceinline__ void walker_run(Walker &w, ParShared &sh, uint8_t *stg /* stg[0] <-> offset seg_lo */,
+                                           uint32_t seg_lo, uint32_t seg_hi)
+{
+    while (!w.done && w.off < seg_hi) {
+        if (w.pos >= w.limit) { w.done = 1; break; }
+        if (w.nb < 32) { w.buf |= (uint64_t)sh.win[w.wi++] << w.nb; w.nb += 32; }
+        {
+            const uint32_t idx = (uint32_t)w.buf & ((1u << LBITS) - 1u);
+            const uint32_t t = sh.tb[idx];
+            const uint32_t n = sh.tn[idx];
+            if (t - 1u < (uint32_t)MAXTOK && n != 0xffffu) {
+                if (n == 1u) { /* literal */
+                    const uint32_t rel = w.off - seg_lo;
+                    stg[rel] = (uint8_t)sh.lit.lut[idx];
+                    atomicOr(&sh.bitmap[rel >> 5], 1u << (rel & 31u));
+                }
+                w.buf >>= t; w.nb -= (int)t; w.pos += t;
+                w.off += n;
+                continue;
+            }
+        }
+        const uint32_t d = huff_decode(sh.lit, (uint32_t)w.buf);
+        if (d == 0xffffffffu) { w.done = 1; break; }
+        const int l = (int)(d >> 16);
+        const uint32_t sym = d & 0xffffu;
+        w.buf >>= l; w.nb -= l; w.pos += (uint32_t)l;
+        if (sym < 256u) {
+            const uint32_t rel = w.off - seg_lo;
+            stg[rel] = (uint8_t)sym;
+            atomicOr(&sh.bitmap[rel >> 5], 1u << (rel & 31u));
+            w.off++;
+        } else if (sym == 256u) {
+            w.done = 1;
+        } else {
+            const int lc = (int)sym - 257;
+            const int xb = len_extra_bits(lc);
+            w.off += base_len_of(lc) + ((uint32_t)w.buf & ((1u << xb) - 1u));
+            w.buf >>= xb; w.nb -= xb; w.pos += (uint32_t)xb;
+            if (w.nb < 32) { w.buf |= (uint64_t)sh.win[w.wi++] << w.nb; w.nb += 32; }
+            const uint32_t dd = huff_decode_dist(sh.dist, (uint32_t)w.buf);
+            const int dl = (int)(dd >> 16), dc = (int)(dd & 0xffffu);
+            const int dxb = dc < 4 ? 0 : (dc >> 1) - 1;
+            w.buf >>= (dl + dxb); w.nb -= dl + dxb; w.pos += (uint32_t)(dl + dxb);
+        }
+    }
+}
+constexpr uint32_t STG_BYTES = 32768u;   /* output bytes staged per flush */
 
 /* exclusive prefix sum over the 1024 threads of the workgroup; *total = sum of all */
 __device__ __forceinline__ uint32_t block_excl_sum_pt(uint32_t v, uint32_t *wtot /* [16] shared */, uint32_t *total)
@@ -372,13 +521,155 @@ __device__ __forceinline__ uint32_t stage_bits(uint32_t *dst, int nwords, const 
     return (uint32_t)(gbit & 31u);
 }
 
+/* The code lengths of a dynamic block (RFC 1951 3.2.7) are themselves a Huffman + run-length coded
+ * sequence of up to 316 symbols.  Wave 0 resolves it with the same exact machinery as the block body,
+ * in miniature and without any barrier: 64 pieces of 72 bits, 4-bit exit functions (a code-length
+ * token is at most 7 + 7 bits) in one 64-bit register, a Kogge-Stone composition, a count walk, a
+ * wave scan, a write walk.  The sequence has no end marker: it stops when nlen + ndist lengths have
+ * been produced, so pieces past the end simply decode garbage that is never used. */
+constexpr int HB = 72; /* header bits per lane */
+
+__device__ __forceinline__ uint32_t hdr_peek14(const ParShared &sh, uint32_t p)
+{
+    const uint32_t i = p >> 5;
+    const unsigned long long v = ((unsigned long long)sh.win[i] | ((unsigned long long)sh.win[i + 1] << 32)) >> (p & 31u);
+    return (uint32_t)v & 0x3fffu;
+}
+/* token at the low bits of v: bits | produced << 8 | kind << 16 (kind 0 literal length, 1 repeat
+ * previous, 2 zeros) | literal value << 24; 0 = invalid */
+__device__ __forceinline__ uint32_t hdr_token(const ParShared &sh, uint32_t v)
+{
+    const uint32_t be = sh.bllut[v & 127u];
+    if (!be) return 0;
+    const uint32_t bl = be >> 9, sym = be & 511u;
+    if (sym < 16u) return bl | (1u << 8) | (sym << 24);
+    if (sym == 16u) return (bl + 2u) | ((3u + ((v >> bl) & 3u)) << 8) | (1u << 16);
+    if (sym == 17u) return (bl + 3u) | ((3u + ((v >> bl) & 7u)) << 8) | (2u << 16);
+    return (bl + 7u) | ((11u + ((v >> bl) & 127u)) << 8) | (2u << 16);
+}
+
+__device__ __forceinline__ void hdr_lengths_wave0(ParShared &sh, int lane, uint32_t cur, uint32_t lead, bool prof)
+{
+#define HPH(i) do { if (prof && lane == 0) { const unsigned long long n_ = (unsigned long long)clock64(); sh.acc[i] += n_ - sh.tp; sh.tp = n_; } } while (0)
+    const uint32_t hbase = sh.hpos + 3u * sh.ncode;
+    const uint32_t total = sh.nlen + sh.ndist;
+    const uint32_t ps = hbase + (uint32_t)(HB * lane);
+    /* exit function of my 72-bit piece: entry d-1 = exit of position p+d, 4 bits, 15 = invalid.
+     * Three groups of 24 positions; each group's 38 bits are cut out of the LDS words once, then the
+     * 24 table lookups are independent (unrolled) and only the shift-register update is a chain. */
+    unsigned long long E = 0;
+    for (int g = 2; g >= 0; g--) {
+        const uint32_t p0 = ps + 24u * (uint32_t)g;
+        const uint32_t wi = p0 >> 5, b0 = p0 & 31u;
+        const unsigned long long w01 = (unsigned long long)sh.win[wi] | ((unsigned long long)sh.win[wi + 1] << 32);
+        const unsigned long long w12 = (w01 >> 32) | ((unsigned long long)sh.win[wi + 2] << 32);
+        /* chunk bit j = stream bit p0 + j, j in [0, 64): b0 + 38 <= 69, so splice at the word boundary */
+        const unsigned long long chunk = b0 ? ((w01 >> b0) | ((w12 >> 32) << (64u - b0))) : w01;
+        uint32_t tk[24];
+#pragma unroll
+        for (int j = 0; j < 24; j++) tk[j] = hdr_token(sh, (uint32_t)(chunk >> j) & 0x3fffu);
+#pragma unroll
+        for (int j = 23; j >= 0; j--) {
+            const uint32_t k = 24u * (uint32_t)g + (uint32_t)j;
+            const uint32_t t = tk[j] & 255u;
+            unsigned long long ex;
+            if (!tk[j]) ex = 15;
+            else if (k + t >= (uint32_t)HB) ex = k + t - (uint32_t)HB;
+            else ex = (E >> (4u * (t - 1u))) & 15ull;
+            E = (E << 4) | ex;
+        }
+    }
+    HPH(17);
+    /* inclusive composition over the lanes */
+    unsigned long long inc = E;
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const unsigned long long y = __shfl_up(inc, dd);
+        if (lane >= dd) {
+            unsigned long long r = 0;
+#pragma unroll
+            for (int e = 0; e < 14; e++) {
+                const uint32_t v = (uint32_t)(y >> (4 * e)) & 15u;
+                const unsigned long long o = v == 15u ? 15ull : ((inc >> (4u * v)) & 15ull);
+                r |= o << (4 * e);
+            }
+            inc = r;
+        }
+    }
+    const unsigned long long exc = __shfl_up(inc, 1);
+    const uint32_t entry = lane == 0 ? 0u : (uint32_t)(exc & 15ull);
+    HPH(18);
+    /* count walk */
+    uint32_t cnt = 0, lastinfo = 0;
+    if (entry != 15u) {
+        uint32_t pos = ps + entry;
+        while (pos < ps + (uint32_t)HB) {
+            const uint32_t tk = hdr_token(sh, hdr_peek14(sh, pos));
+            if (!tk) break;
+            pos += tk & 255u;
+            cnt += (tk >> 8) & 255u;
+            const uint32_t kind = (tk >> 16) & 3u;
+            if (kind == 0u) lastinfo = 0x100u | (tk >> 24);
+            else if (kind == 2u) lastinfo = 0x100u;
+        }
+    }
+    uint32_t tot;
+    const uint32_t offs = wave_excl_sum(cnt, &tot);
+    /* length a leading "repeat previous" refers to */
+    uint32_t x = lastinfo;
+    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(x, dd); if (lane >= dd && !x) x = y; }
+    uint32_t prev = __shfl_up(x, 1);
+    if (lane == 0) prev = 0;
+    HPH(19);
+    /* write walk */
+    uint32_t endpos = 0xffffffffu, bad = 0;
+    if (entry != 15u && offs < total) {
+        uint32_t pos = ps + entry, idx = offs;
+        uint32_t pv = prev & 0xffu;
+        bool hp = (prev & 0x100u) != 0;
+        while (pos < ps + (uint32_t)HB && idx < total) {
+            const uint32_t tk = hdr_token(sh, hdr_peek14(sh, pos));
+            if (!tk) { bad = 1; break; }
+            pos += tk & 255u;
+            const uint32_t n = (tk >> 8) & 255u, kind = (tk >> 16) & 3u;
+            uint32_t val;
+            if (kind == 0u) { val = tk >> 24; pv = val; hp = true; }
+            else if (kind == 1u) { if (!hp) { bad = 1; break; } val = pv; }
+            else { val = 0; pv = 0; hp = true; }
+            if (idx + n > total) { bad = 1; break; }
+            for (uint32_t k = 0; k < n; k++) sh.lens[idx + k] = (uint8_t)val;
+            idx += n;
+            if (idx == total) endpos = pos;
+        }
+    } else if (entry == 15u && offs < total) bad = 1;
+    const unsigned long long anybad = __ballot(bad != 0);
+    const unsigned long long found = __ballot(endpos != 0xffffffffu);
+    if (anybad || !found || tot < total) {
+        if (lane == 0) sh.status = 2; /* the sequential decoder re-parses and reports real errors */
+    } else if (endpos != 0xffffffffu) {
+        sh.cur = cur + (endpos - lead);
+    }
+#undef HPH
+}
+
 __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                     const DecStream *__restrict__ ds, uint8_t *__restrict__ planes,
-                                                    uint32_t *__restrict__ fallback)
+                                                    uint32_t *__restrict__ fallback,
+                                                    unsigned long long *__restrict__ dbg /* NULL, or 8 phase counters per stream */)
 {
-    __shared__ ParShared sh;
+    HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
+    ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
+    uint8_t *stg = reinterpret_cast<uint8_t *>(dynsm) + ((sizeof(ParShared) + 15u) & ~(size_t)15u);
     const int tid = threadIdx.x;
     const uint32_t s = blockIdx.x;
+    /* optional phase counters live in LDS so that they cost no registers */
+#define PHASE(i)                                                         \
+    do {                                                                 \
+        if (dbg && tid == 0) {                                           \
+            const unsigned long long now_ = (unsigned long long)clock64(); \
+            sh.acc[i] += now_ - sh.tp;                                   \
+            sh.tp = now_;                                                \
+        }                                                                \
+    } while (0)
     const DecStream d = ds[s];
     uint8_t *out = planes + (size_t)s * CHK;
     if (tid == 0) fallback[s] = 0;
@@ -403,15 +694,15 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
     if (tid == 0) { sh.cur = 0; sh.op = 0; sh.last = 0; sh.status = 0; }
     __syncthreads();
 
+    if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
     for (;;) {
         /* ------------------------------------------------ block header ------------------------------------------------ */
         if (sh.status != 0) break;
+        if (dbg && tid == 0) sh.acc[10]++;
         const uint32_t cur = sh.cur;
         if (sh.op >= d.n) { if (tid == 0) sh.status = 1; __syncthreads(); break; }
         if (cur + 3u > paybits) { if (tid == 0) sh.status = 2; __syncthreads(); break; }
         const uint32_t lead = stage_bits(sh.win, HDR_WORDS, rec, reclen, paybit0, cur);
-        for (int i = tid; i < (1 << LBITS); i += PT) { sh.lit.lut[i] = 0; sh.dist.lut[i] = 0; }
-        if (tid < 128) sh.bllut[tid] = 0;
         if (tid < 19) sh.bl[tid] = 0;
         __syncthreads();
         if (tid == 0) {
@@ -454,44 +745,10 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
                 sh.bl[k_bl_order(tid)] = (uint8_t)(v & 7u);
             }
             __syncthreads();
+            PHASE(12);
             huff_build(sh.dist, sh.bl, 19, tid, sh.bllut, 7);
-            if (tid == 0) {
-                /* the code lengths themselves: a short sequential Huffman + run-length decode */
-                LdsBits lb;
-                lb.w = sh.win;
-                lb.pos = sh.hpos + 3u * sh.ncode;
-                const int total = (int)(sh.nlen + sh.ndist);
-                int idx = 0;
-                bool bad = false;
-                uint32_t wi = lb.pos >> 5;
-                unsigned long long buf = ((unsigned long long)sh.win[wi] | ((unsigned long long)sh.win[wi + 1] << 32)) >> (lb.pos & 31u);
-                int nb = 64 - (int)(lb.pos & 31u);
-                uint32_t pos = lb.pos;
-                wi += 2;
-                int prev = 0;
-                while (idx < total) {
-                    if (nb < 32) { buf |= (unsigned long long)sh.win[wi++] << nb; nb += 32; }
-                    const uint32_t be = sh.bllut[(uint32_t)buf & 127u];
-                    if (!be) { bad = true; break; }
-                    const int bl = (int)(be >> 9), sym = (int)(be & 511u);
-                    buf >>= bl; nb -= bl; pos += (uint32_t)bl;
-                    if (sym < 16) { sh.lens[idx++] = (uint8_t)sym; prev = sym; }
-                    else {
-                        int rep, val = 0, xb;
-                        if (sym == 16) { if (idx == 0) { bad = true; break; } val = prev; xb = 2; rep = 3; }
-                        else if (sym == 17) { xb = 3; rep = 3; prev = 0; }
-                        else { xb = 7; rep = 11; prev = 0; }
-                        rep += (int)((uint32_t)buf & ((1u << xb) - 1u));
-                        buf >>= xb; nb -= xb; pos += (uint32_t)xb;
-                        if (idx + rep > total) { bad = true; break; }
-                        for (int k = 0; k < rep; k++) sh.lens[idx + k] = (uint8_t)val;
-                        idx += rep;
-                    }
-                    if (pos > (uint32_t)(HDR_WORDS - 3) * 32u) { bad = true; break; }
-                }
-                if (bad) sh.status = 2;
-                sh.cur = cur + (pos - lead);
-            }
+            PHASE(13);
+            if (tid < 64) hdr_lengths_wave0(sh, tid, cur, lead, dbg != nullptr);
             __syncthreads();
             if (sh.status != 0) break;
         }
@@ -512,10 +769,16 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
             __syncthreads();
             continue;
         }
+        PHASE(14);
         huff_build(sh.lit, sh.lens, (int)sh.nlen, tid, sh.lit.lut, LBITS);
-        if (tid < (1 << LBITS)) sh.dist.lut[tid] = 0; /* held the code-length code's ranks until now */
-        __syncthreads();
-        huff_build(sh.dist, sh.lens + sh.nlen, (int)sh.ndist, tid, sh.dist.lut, LBITS);
+        PHASE(15);
+        huff_build(sh.dist, sh.lens + sh.nlen, (int)sh.ndist, tid, sh.dist.lut, DBITS);
+        PHASE(16);
+        for (int i = tid; i < (1 << LBITS); i += PT) {
+            uint32_t nby;
+            sh.tb[i] = (uint8_t)fast_token_entry(sh, (uint32_t)i, &nby);
+            sh.tn[i] = (uint16_t)nby;
+        }
         /* longest token of this block: bounds the exit-function domain */
         if (tid == 0) { sh.dmax = 0; sh.maxtok = 1; }
         __syncthreads();
@@ -532,17 +795,20 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
         if (tid == 0 && sh.maxtok > (uint32_t)MAXTOK) sh.maxtok = MAXTOK;
         __syncthreads();
 
+        PHASE(0);
         /* ------------------------------------------------ block body, window by window ------------------------------------------------ */
         for (;;) {
+            if (dbg && tid == 0) sh.acc[11]++;
             const uint32_t wcur = sh.cur;
             const uint32_t wlead = stage_bits(sh.win, WIN_WORDS, rec, reclen, paybit0, wcur);
             __syncthreads();
+            PHASE(1);
             const uint32_t pstart = wlead + (uint32_t)tid * SUBBITS;
             const uint32_t limit = pstart + SUBBITS;
             /* P1: exit function of my piece */
             const ExitFn mine = piece_exit_fn(sh, pstart);
+            PHASE(2);
             /* P2: inclusive Kogge-Stone scan of function composition across the wave */
-            const uint32_t maxtok = sh.maxtok;
             ExitFn inc = mine;
             {
                 const int l = lane_id();
@@ -550,7 +816,7 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
                     ExitFn y;
                     y.lo = __shfl_up(inc.lo, dd);
                     y.hi = __shfl_up(inc.hi, dd);
-                    if (l >= dd) inc = fn_compose(y, inc, maxtok);
+                    if (l >= dd) inc = fn_compose(y, inc);
                 }
                 if (l == 63) { sh.fnlo[tid >> 6] = inc.lo; sh.fnhi[tid >> 6] = inc.hi; }
             }
@@ -567,10 +833,12 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
             if (lane_id() != 0 && entry < (uint32_t)MAXTOK) entry = fn_get(exc, entry);
             __syncthreads();
             const uint32_t start = entry < (uint32_t)MAXTOK ? pstart + entry : POS_INVALID;
+            PHASE(3);
             /* P3: walk from the true entry, counting */
             SubResult r;
-            if (start != POS_INVALID) r = decode_sub<false>(sh, start, limit, nullptr, 0);
+            if (start != POS_INVALID) r = count_walk(sh, start, limit);
             else { r.land = POS_INVALID; r.nout = 0; r.flags = (entry == X_ERR) ? F_ERR : 0; r.lastlit = 0; }
+            PHASE(4);
             /* first lane that ended the block (or failed); lanes after it are inactive */
             const uint32_t e = block_min_pt((r.flags & (F_EOB | F_ERR)) ? (uint32_t)tid : 0xffffffffu, sh.scan_a);
             const bool active = start != POS_INVALID;
@@ -581,24 +849,65 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
             const uint32_t bad_flags = sh.flag;
             uint32_t total;
             const uint32_t myoff = block_excl_sum_pt(active ? r.nout : 0u, sh.scan_a, &total);
-            const uint32_t inlast = block_excl_last_pt(active ? r.lastlit : 0u, sh.scan_b);
+            PHASE(5);
             const uint32_t op = sh.op;
             if (bad_flags || op + total > d.n) {
                 if (tid == 0) sh.status = (bad_flags & F_GENERAL) ? 3 : 2;
                 __syncthreads();
                 break;
             }
-            if (active && r.nout) {
-                const uint32_t inb = inlast ? (inlast & 0xffu) : sh.last;
-                decode_sub<true>(sh, start, limit, out + op + myoff, inb);
+            {
+                Walker wk;
+                if (active && r.nout) walker_init(wk, sh, start, limit, myoff);
+                else { wk.buf = 0; wk.pos = 0; wk.limit = 0; wk.wi = 0; wk.nb = 0; wk.done = 1; wk.off = 0; }
+                uint32_t carry = sh.last; /* byte that precedes the segment */
+                for (uint32_t seg = 0; seg < total; seg += STG_BYTES) {
+                    const uint32_t seg_hi = seg + STG_BYTES < total ? seg + STG_BYTES : total;
+                    uint8_t *dst = out + op + seg;
+                    const uint32_t lead = (uint32_t)((uintptr_t)dst & 15u);
+                    sh.bitmap[tid] = 0; /* PT words x 32 = STG_BYTES positions */
+                    __syncthreads();
+                    if (!wk.done && wk.off < seg_hi) walker_run(wk, sh, stg + lead, seg, seg_hi);
+                    PHASE(6);
+                    __syncthreads();
+                    PHASE(7);
+                    /* forward fill: thread t owns positions [32t, 32t+32) of the segment */
+                    {
+                        const uint32_t word = sh.bitmap[tid];
+                        uint8_t *q = stg + lead + 32u * (uint32_t)tid;
+                        const uint32_t mylast = word ? (0x100u | q[31 - __builtin_clz(word)]) : 0u;
+                        const uint32_t inl = block_excl_last_pt(mylast, sh.scan_b);
+                        uint32_t v = inl ? (inl & 0xffu) : carry;
+                        const uint32_t nvalid = seg_hi - seg;
+                        if (32u * (uint32_t)tid < nvalid) {
+#pragma unroll 8
+                            for (uint32_t i = 0; i < 32u; i++) {
+                                if ((word >> i) & 1u) v = q[i];
+                                else q[i] = (uint8_t)v;
+                            }
+                        }
+                        /* byte preceding the next segment = value after the last valid position */
+                        if (tid == PT - 1) sh.flag = word ? (mylast & 0xffu) : (inl ? (inl & 0xffu) : carry);
+                    }
+                    __syncthreads();
+                    carry = sh.flag;
+                    /* flush: stage byte i <-> dst[i - lead]; 16-byte units, partial first/last unit by bytes */
+                    const uint32_t nb = seg_hi - seg;
+                    const uint32_t nunits = (lead + nb + 15u) >> 4;
+                    for (uint32_t u = tid; u < nunits; u += PT) {
+                        const uint32_t lo = 16u * u, hi = lo + 16u;
+                        if (lo >= lead && hi <= lead + nb) {
+                            *reinterpret_cast<uint4 *>(dst - lead + lo) = *reinterpret_cast<const uint4 *>(stg + lo);
+                        } else {
+                            const uint32_t a0 = lo < lead ? lead : lo, a1 = hi > lead + nb ? lead + nb : hi;
+                            for (uint32_t i = a0; i < a1; i++) dst[i - lead] = stg[i];
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (tid == 0 && total) sh.last = carry; /* last byte this window produced */
             }
-            /* last byte produced by this window */
-            const uint32_t lastall = block_excl_last_pt(active ? r.lastlit : 0u, sh.scan_b); /* value before each lane */
-            if (tid == PT - 1) {
-                const uint32_t lastb = (active && r.lastlit) ? r.lastlit : lastall;
-                if (lastb) sh.last = lastb & 0xffu;
-                sh.op = op + total;
-            }
+            if (tid == PT - 1) sh.op = op + total;
             if (e != 0xffffffffu) {
                 if ((uint32_t)tid == e) {
                     sh.cur = wcur + (r.land - wlead); /* r.land is just past END_BLOCK */
@@ -608,6 +917,7 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
                 sh.cur = wcur + (r.land - wlead);
             }
             __syncthreads();
+            PHASE(8);
             if (e != 0xffffffffu) break; /* next block */
             if (sh.cur > paybits) { if (tid == 0) sh.status = 2; __syncthreads(); break; }
         }
@@ -617,7 +927,9 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
         if (sh.status == 1 && sh.op != d.n) sh.status = 2;
         /* 2 and 3 both hand the stream to the sequential decoder, which reports real format errors */
         fallback[s] = (sh.status == 1) ? 0u : 1u;
+        if (dbg) for (int i = 0; i < 20; i++) dbg[(size_t)s * 20 + i] = sh.acc[i];
     }
+#undef PHASE
 }
 
 } /* namespace mrcz */

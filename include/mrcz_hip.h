@@ -113,6 +113,14 @@ int mrcz_debug_blocks(mrcz_ctx_t *ctx, uint32_t stream, mrcz_block_info_t *block
  * Z_RLE wrote). */
 int64_t mrcz_debug_fallbacks(const mrcz_ctx_t *ctx);
 
+/* Inspection (profiling): enable/disable the in-kernel phase counters of the parallel inflate and
+ * (if out != NULL) read the 20 counters of `stream` from the last call (shader clocks of thread 0):
+ * [0] header+tables [1] staging [2] exit functions [3] composition [4] count walk [5] scans
+ * [6] literal scatter walk [7] wait for the slowest wave [8] fill + flush [9] - [10] blocks
+ * [11] windows [12..16] header sub-phases (first bits, code-length code, length decode, literal
+ * table, distance table). */
+int mrcz_debug_inflate_phases(mrcz_ctx_t *ctx, int enable, uint32_t stream, uint64_t out[20]);
+
 #ifdef __cplusplus
 }
 #endif

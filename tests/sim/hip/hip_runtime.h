@@ -2,7 +2,7 @@
  * tests/sim/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY (never part of the product build).
  *
  * A minimal single-OS-thread SIMT emulator: it lets the unmodified HIP source of
- * datacompressionfloat_amd/csrc/*.hip be compiled with g++ (this directory is put first on the
+ * the HIP sources under datacompressionfloat_amd/csrc be compiled with g++ (this directory is put first on the
  * include path so `#include <hip/hip_runtime.h>` resolves here) and executed on the CPU, one
  * workgroup at a time, every GPU thread as a ucontext fiber.  Wave size is 64 (gfx950).  The
  * container used to develop this repo has no GPU; this harness exists so that kernel logic can be
@@ -142,3 +142,10 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = 
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e3); return hipSuccess; }
 static inline void __builtin_amdgcn_wave_barrier() { sim_wave_barrier(); }
+static inline long long clock64() { return 0; }
+#define __noinline__ __attribute__((noinline))
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return sim_exchange(v, lane & 63); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return sim_exchange(v, 0); }
+static inline int __builtin_amdgcn_writelane(int v, int lane, int old) { return sim_lane() == (lane & 63) ? v : old; }
