@@ -295,6 +295,55 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
     return MRCZ_OK;
 }
 
+extern "C" int mrcz_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+extern "C" int mrcz_dev_malloc(mrcz_ctx_t *ctx, void **d_ptr, uint64_t bytes)
+{
+    if (!ctx || !d_ptr) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipError_t e = hipMalloc(d_ptr, (size_t)(bytes ? bytes : 16));
+    return e == hipSuccess ? MRCZ_OK : fail(ctx, MRCZ_ENOMEM, "hipMalloc", e);
+}
+extern "C" int mrcz_dev_free(mrcz_ctx_t *ctx, void *d_ptr)
+{
+    if (!ctx) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipFree(d_ptr), "hipFree");
+    return MRCZ_OK;
+}
+extern "C" int mrcz_host_malloc(mrcz_ctx_t *ctx, void **h_ptr, uint64_t bytes)
+{
+    if (!ctx || !h_ptr) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipError_t e = hipHostMalloc(h_ptr, (size_t)(bytes ? bytes : 16));
+    return e == hipSuccess ? MRCZ_OK : fail(ctx, MRCZ_ENOMEM, "hipHostMalloc", e);
+}
+extern "C" int mrcz_host_free(mrcz_ctx_t *ctx, void *h_ptr)
+{
+    if (!ctx) return MRCZ_EINVAL;
+    HIPCHK(hipHostFree(h_ptr), "hipHostFree");
+    return MRCZ_OK;
+}
+extern "C" int mrcz_copy_h2d(mrcz_ctx_t *ctx, void *d_dst, const void *h_src, uint64_t bytes)
+{
+    if (!ctx) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream), "copy h2d");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "sync h2d");
+    return MRCZ_OK;
+}
+extern "C" int mrcz_copy_d2h(mrcz_ctx_t *ctx, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    if (!ctx) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream), "copy d2h");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "sync d2h");
+    return MRCZ_OK;
+}
+
 extern "C" int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, uint64_t first_word_index, int bits)
 {
     if (!ctx || !d_words) return MRCZ_EINVAL;

@@ -1,0 +1,64 @@
+/*
+ * mrc_tar.c -- single-file front-end with the reference's command line
+ * (/root/reference/src/main/mrc_tar.c:82-165): mrc_tar -i <in> -o <out> [-t zip|unzip] [-b 0..32]
+ * [-s float|int] [-h].  The work is done by run_compress / run_uncompress on the GPU.
+ */
+#include "../../include/mrcz_workers.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+static void usage(char **argv) /* mrc_tar.c:82-100 */
+{
+    printf("\nUsage:\n\n\t%s -i <input file> -o <output file> [-t <zip | unzip> -b <bits to erase>]\nwhere:\n", argv[0]);
+    printf("\t-i\tinput file that need to be compressed or decompressed\n\n");
+    printf("\t-o\t output file that being compressed or decompressed \n\n");
+    printf("\t-b\t bits to be erased, range[0..32], default is 0\n\n");
+    printf("\t-s\t data type to be converted to when compressed/decompressed, value should be [float | int], default is float\n\n");
+    printf("\t-t\t operation type, e.g compress or decompressed file, value should be [zip | unzip], default is zip\n\n");
+    printf("\t-g\t HIP device to use, default 0 (extension of the MI355X build)\n\n");
+}
+
+int main(int argc, char *argv[])
+{
+    const char *in = NULL, *out = NULL, *op = "zip", *dtype = "float";
+    int bits = 0, opt;
+    if (argc < 2) { usage(argv); exit(-1); }
+    while ((opt = getopt(argc, argv, "hi:o:b:t:s:g:")) != -1) {
+        switch (opt) {
+        case 'i': in = optarg; break;
+        case 'o': out = optarg; break;
+        case 'b': bits = atoi(optarg); break;
+        case 't': op = optarg; break;
+        case 's': dtype = optarg; break;
+        case 'g': mrcz_workers_set_device(atoi(optarg)); break;
+        case 'h': usage(argv); return 0;
+        default: printf("Invalid command line parameters!\n"); usage(argv); return -1;
+        }
+    }
+    if (!in || !out) { usage(argv); return -1; }
+    printf("CODEC:mrcz-hip gfx950 (DEFLATE Z_RLE stream-compatible with ZLIB:1.2.8)\n"); /* mrc_tar.c:152 prints the zlib version */
+    ctx_t ctx;
+    init_context(&ctx);
+    ctx.fileCount += 1;
+    FILE *fin = fopen(in, "rb");
+    if (!fin) { fprintf(stderr, "Error: [%s:%d]: Failed to  open input file :%s\n", __FILE__, __LINE__, in); exit(-1); }
+    FILE *fout = fopen(out, "wb");
+    if (!fout) { fprintf(stderr, "Error: [%s:%d]: Failed to open output file [%s] to write\n", __FILE__, __LINE__, out); exit(-1); }
+    if (strcmp(op, "zip") == 0) { /* mrc_tar.c:24-54 */
+        ctx.allFileSize += get_file_size(fin);
+        run_compress(fin, &ctx, fout, bits, dtype);
+        print_context_info(&ctx, "Contex Info after Compression");
+    } else if (strcmp(op, "unzip") == 0) { /* mrc_tar.c:56-80 */
+        mrczip_header_t hd;
+        init_mrczip_header(&hd, 0);
+        if (read_mrczip_header(fin, &hd) != 0) { fclose(fin); fclose(fout); return -1; }
+        print_mrczip_header(&hd, "Header Info in Decompression");
+        run_uncompress(fin, &ctx, &hd, fout, dtype);
+        print_context_info(&ctx, "Contex Info after Decompression");
+    }
+    fclose(fout);
+    fclose(fin);
+    return 0;
+}

@@ -1,0 +1,173 @@
+/*
+ * workers_gpu.c -- run_compress / run_uncompress of the reference
+ * (/root/reference/src/core/workers.c:690-881 and :568-688, declared in src/include/workers.h:30-31)
+ * re-implemented as the "chunk scheduler" of the MI355X codec: the file is read in batches of
+ * chunks into pinned host memory by a reader thread while the previous batch is on the GPU
+ * (H2D, include/mrcz_hip.h kernels, D2H), and the chunk records are written in order.  Same
+ * signatures, same container bytes, same ctx side effects; errors that the reference answers
+ * with exit(-1) (workers.c:708-712) do the same here.  There is no CPU codec in this file: if the
+ * HIP library cannot create a context the call fails loudly.
+ */
+#include "../../include/mrcz_hip.h"
+#include "../../include/mrcz_workers.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+int isTestThroughput = 0; /* src/core/workers.c:39 */
+
+static __thread int t_device = 0;
+static __thread int t_batch_chunks = 16;
+
+void mrcz_workers_set_device(int device) { t_device = device; }
+void mrcz_workers_set_batch_chunks(int chunks) { t_batch_chunks = chunks < 1 ? 1 : (chunks > 128 ? 128 : chunks); }
+
+static void die(const char *what, mrcz_ctx_t *c)
+{
+    fprintf(stderr, "[%s:%d] ERROR: %s: %s\n", __FILE__, __LINE__, what, c ? mrcz_last_error(c) : "");
+    exit(-1);
+}
+
+/* ---- double-buffered reader: fread of batch k+1 overlaps the GPU work on batch k ---- */
+typedef struct {
+    FILE *f;
+    void *buf;
+    size_t elem, want, got;
+} read_job_t;
+static void *read_thread(void *arg)
+{
+    read_job_t *j = (read_job_t *)arg;
+    j->got = fread(j->buf, j->elem, j->want, j->f);
+    return NULL;
+}
+
+int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const char *dataConvertedType)
+{
+    if (dataConvertedType && strcmp(dataConvertedType, "float") != 0) {
+        /* "-s int" (workers.c:125-175,782-787) is a separate lossy mode outside the GPU hot path */
+        fprintf(stderr, "[%s:%d] ERROR: only the float mode is implemented on the GPU path (got '%s')\n", __FILE__, __LINE__,
+                dataConvertedType);
+        exit(-1);
+    }
+    if (bitsToMask < 0 || bitsToMask > 32) {
+        fprintf(stderr, "[%s:%d] ERROR: bits to erase must be in 0..32 (table of 33 masks, workers.c:29-37)\n", __FILE__, __LINE__);
+        exit(-1);
+    }
+    double begin = now_sec();
+    mrcz_ctx_t *c = NULL;
+    if (mrcz_create(&c, t_device, (uint32_t)t_batch_chunks) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
+    const uint64_t batch_floats = (uint64_t)t_batch_chunks * CHUNK_SIZE;
+    const uint64_t rec_cap = mrcz_records_bound(batch_floats);
+    void *h_in[2] = {NULL, NULL}, *h_out = NULL, *d_in = NULL, *d_out = NULL;
+    if (mrcz_host_malloc(c, &h_in[0], batch_floats * 4) || mrcz_host_malloc(c, &h_in[1], batch_floats * 4) ||
+        mrcz_host_malloc(c, &h_out, rec_cap) || mrcz_dev_malloc(c, &d_in, batch_floats * 4) || mrcz_dev_malloc(c, &d_out, rec_cap))
+        die("fail to alloc mem", c);
+
+    mrczip_header_t hd;
+    init_mrczip_header(&hd, 0);
+    hd.chk = CHUNK_SIZE;            /* workers.c:735 */
+    hd.fsz = get_file_size(fin);    /* workers.c:743: the true size, also when it is not a multiple of 4 */
+    ctx->zipTime += now_sec() - begin;
+
+    uint64_t plane_total[4] = {0, 0, 0, 0};
+    uint64_t first_chunk = 0;
+    int cur = 0;
+    read_job_t job = {fin, h_in[0], sizeof(uint32_t), (size_t)batch_floats, 0};
+    read_thread(&job); /* first batch, synchronously (workers.c:744) */
+    size_t num = job.got;
+    if (num > 0 && isTestThroughput != 1) write_mrczip_header(fout, &hd); /* workers.c:757-765 */
+    while (num > 0) {
+        /* start reading the next batch while this one is compressed */
+        pthread_t th;
+        read_job_t next = {fin, h_in[cur ^ 1], sizeof(uint32_t), (size_t)batch_floats, 0};
+        const int more = (num == (size_t)batch_floats);
+        if (more && pthread_create(&th, NULL, read_thread, &next) != 0) die("pthread_create", NULL);
+        begin = now_sec();
+        uint64_t out_len = 0, planes[4];
+        if (mrcz_copy_h2d(c, d_in, h_in[cur], (uint64_t)num * 4)) die("H2D copy", c);
+        if (mrcz_compress_chunks(c, d_in, (uint64_t)num, first_chunk, bitsToMask, d_out, rec_cap, &out_len, planes)) die("compress", c);
+        if (isTestThroughput != 1) {
+            if (mrcz_copy_d2h(c, h_out, d_out, out_len)) die("D2H copy", c);
+        }
+        ctx->zipTime += now_sec() - begin;
+        for (int j = 0; j < 4; j++) plane_total[j] += planes[j];
+        if (isTestThroughput != 1) fwrite(h_out, 1, (size_t)out_len, fout); /* workers.c:837-850 */
+        first_chunk += (num + CHUNK_SIZE - 1) / CHUNK_SIZE;
+        if (more) {
+            pthread_join(th, NULL);
+            num = next.got;
+            cur ^= 1;
+        } else num = 0;
+    }
+    /* workers.c:870-873: sum of the per-plane compressed sizes (each includes its 4-byte header) */
+    for (int j = 0; j < 4; j++) ctx->allZipFileSize += plane_total[j];
+    mrcz_host_free(c, h_in[0]); mrcz_host_free(c, h_in[1]); mrcz_host_free(c, h_out);
+    mrcz_dev_free(c, d_in); mrcz_dev_free(c, d_out);
+    mrcz_destroy(c);
+    return 0;
+}
+
+int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const char *dataConvertedType)
+{
+    if (dataConvertedType && strcmp(dataConvertedType, "float") != 0) {
+        fprintf(stderr, "[%s:%d] ERROR: only the float mode is implemented on the GPU path (got '%s')\n", __FILE__, __LINE__,
+                dataConvertedType);
+        exit(-1);
+    }
+    for (int j = 0; j < COMPRESSION_PATH_NUM; j++)
+        if (hd->ztypes[j] != 0) { /* LZ4 / LZ4HC streams are never written by the reference (workers.c:719) */
+            fprintf(stderr, "[%s:%d] ERROR: byte stream %d uses compressor type %d; only ZLIB_DEF (0) is supported\n", __FILE__, __LINE__,
+                    j, hd->ztypes[j]);
+            exit(-1);
+        }
+    if (hd->chk == 0 || hd->chk > CHUNK_SIZE) { /* the reference divides by chk (workers.c:589) */
+        fprintf(stderr, "[%s:%d] ERROR: bad chunk size %u in header\n", __FILE__, __LINE__, hd->chk);
+        exit(-1);
+    }
+    double start = now_sec();
+    const uint64_t nfloats = hd->fsz / COMPRESSION_PATH_NUM; /* workers.c:577 */
+    const uint32_t chk = hd->chk;
+    mrcz_ctx_t *c = NULL;
+    if (mrcz_create(&c, t_device, (uint32_t)t_batch_chunks) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
+    const uint64_t batch_floats = (uint64_t)t_batch_chunks * chk;
+    const uint64_t rec_cap = mrcz_records_bound((uint64_t)t_batch_chunks * CHUNK_SIZE) + 64;
+    void *h_rec = NULL, *h_out = NULL, *d_rec = NULL, *d_out = NULL;
+    if (mrcz_host_malloc(c, &h_rec, rec_cap) || mrcz_host_malloc(c, &h_out, batch_floats * 4) ||
+        mrcz_dev_malloc(c, &d_rec, rec_cap) || mrcz_dev_malloc(c, &d_out, batch_floats * 4))
+        die("fail to alloc mem", c);
+    ctx->unzipTime += now_sec() - start;
+
+    uint64_t done = 0, zbytes = 0;
+    while (done < nfloats) {
+        const uint64_t nfl = (nfloats - done) < batch_floats ? (nfloats - done) : batch_floats;
+        const uint64_t nchunks = (nfl + chk - 1) / chk;
+        /* read the batch's records: walk the 16-byte chunk headers (workers.c:52-69) */
+        uint64_t len = 0;
+        for (uint64_t k = 0; k < nchunks; k++) {
+            unsigned char *h = (unsigned char *)h_rec + len;
+            if (len + 16 > rec_cap || fread(h, 1, 16, fin) != 16) die("truncated container (chunk header)", NULL);
+            uint64_t pay = 0;
+            for (int j = 0; j < 4; j++) /* unpack_header, zip.c:393-399 */
+                pay += (uint64_t)h[4 * j] | ((uint64_t)h[4 * j + 1] << 8) | ((uint64_t)h[4 * j + 2] << 16) | ((uint64_t)(h[4 * j + 3] & 0x7f) << 24);
+            if (len + 16 + pay > rec_cap || fread(h + 16, 1, (size_t)pay, fin) != pay) die("truncated container (payload)", NULL);
+            len += 16 + pay;
+        }
+        start = now_sec();
+        uint64_t consumed = 0;
+        if (mrcz_copy_h2d(c, d_rec, h_rec, len)) die("H2D copy", c);
+        if (mrcz_uncompress_chunks(c, d_rec, len, nfl, chk, d_out, &consumed)) die("uncompress", c);
+        if (isTestThroughput != 1) {
+            if (mrcz_copy_d2h(c, h_out, d_out, nfl * 4)) die("D2H copy", c);
+        }
+        ctx->unzipTime += now_sec() - start;
+        if (isTestThroughput != 1) fwrite(h_out, sizeof(float), (size_t)nfl, fout); /* workers.c:627,668 */
+        done += nfl;
+        zbytes += len;
+    }
+    /* workers.c:679-685: decoded bytes and compressed bytes (plane payloads; chunk headers are not counted there) */
+    ctx->allFileSize += nfloats * 4;
+    ctx->allZipFileSize += zbytes - 16 * ((nfloats + chk - 1) / chk);
+    mrcz_host_free(c, h_rec); mrcz_host_free(c, h_out); mrcz_dev_free(c, d_rec); mrcz_dev_free(c, d_out);
+    mrcz_destroy(c);
+    return 0;
+}

@@ -86,6 +86,16 @@ int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, ui
 int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats,
                            uint32_t chk, void *d_out, uint64_t *consumed);
 
+/* Plain-C device memory helpers so that C host code (the C files under datacompressionfloat_amd/host) needs no HIP
+ * headers: device buffers, pinned host buffers, synchronous copies on the context's stream. */
+int mrcz_device_count(void);
+int mrcz_dev_malloc(mrcz_ctx_t *ctx, void **d_ptr, uint64_t bytes);
+int mrcz_dev_free(mrcz_ctx_t *ctx, void *d_ptr);
+int mrcz_host_malloc(mrcz_ctx_t *ctx, void **h_ptr, uint64_t bytes); /* pinned */
+int mrcz_host_free(mrcz_ctx_t *ctx, void *h_ptr);
+int mrcz_copy_h2d(mrcz_ctx_t *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int mrcz_copy_d2h(mrcz_ctx_t *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+
 /* apply_mask alone on device (the erasebytes restatement used by the GPU-side verification tools,
  * src/tool/erasebytes.c:109-134): words [256, nwords) of a file &= mask(bits).  In place. */
 int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, uint64_t first_word_index, int bits);

@@ -1,0 +1,94 @@
+"""GPU: the C front-ends (same command line as the reference's mrc_tar_c / mrc_tarx_c) write the
+reference's bytes and read the reference's files."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(util.ROOT, "datacompressionfloat_amd", "bin")
+
+
+def _run(args, **kw):
+    return subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, **kw)
+
+
+def test_mrc_tar_zip_unzip_matches_oracle(tmp_path, oracle):
+    exe = os.path.join(BIN, "mrc_tar")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    for n, bits in ((100, 0), (70001, 8), (util.CHUNK + 12345, 8), (3 * util.CHUNK + 5, 12)):
+        w = util.gauss_words(n, seed=n & 1023)
+        src, dst, back = tmp_path / "in.mrc", tmp_path / "out.zip", tmp_path / "back.mrc"
+        data = w.tobytes() + (b"xyz" if n == 70001 else b"")
+        src.write_bytes(data)
+        r = _run([exe, "-i", str(src), "-o", str(dst), "-b", str(bits), "-t", "zip"])
+        assert r.returncode == 0, r.stderr
+        assert dst.read_bytes() == oracle.compress(data, bits)
+        r = _run([exe, "-i", str(dst), "-o", str(back), "-t", "unzip"])
+        assert r.returncode == 0, r.stderr
+        assert back.read_bytes() == util.erase_expected(w, bits).tobytes()
+
+
+def test_mrc_tar_rejects_bad_arguments(tmp_path):
+    exe = os.path.join(BIN, "mrc_tar")
+    src = tmp_path / "in.mrc"
+    src.write_bytes(util.gauss_words(1000).tobytes())
+    assert _run([exe, "-i", str(src), "-o", str(tmp_path / "o"), "-b", "33"]).returncode != 0
+    assert _run([exe, "-i", str(tmp_path / "missing"), "-o", str(tmp_path / "o")]).returncode != 0
+    assert _run([exe, "-i", str(src), "-o", str(tmp_path / "o"), "-s", "int"]).returncode != 0  # float mode only
+
+
+def test_mrc_tarx_file_list_naming_and_threads(tmp_path, oracle):
+    exe = os.path.join(BIN, "mrc_tarx")
+    srcdir, zdir, udir = tmp_path / "src", tmp_path / "z", tmp_path / "u"
+    for d in (srcdir, zdir, udir):
+        d.mkdir()
+    names, datas = [], {}
+    for i, n in enumerate((5000, 300000, util.CHUNK + 77)):
+        p = srcdir / f"stack{i}.mrc"
+        w = util.poisson_words(n, seed=i)
+        p.write_bytes(w.tobytes())
+        names.append(str(p))
+        datas[f"stack{i}"] = w
+    lst = tmp_path / "files.txt"
+    lst.write_text("\n".join(names) + "\n")
+    r = _run([exe, "-i", str(lst), "-t", "zip", "-o", str(zdir), "-b", "8", "-n", "2"])
+    assert r.returncode == 0, r.stderr
+    assert "MB/s" in r.stdout                                   # mrc_tarx.c:231 summary line
+    znames = []
+    for stem, w in datas.items():
+        z = zdir / f"{stem}.mrc.zip"                            # adapt.c:303-305 naming
+        assert z.read_bytes() == oracle.compress(w.tobytes(), 8)
+        znames.append(str(z))
+    lst2 = tmp_path / "zips.txt"
+    lst2.write_text("\n".join(znames) + "\n")
+    r = _run([exe, "-i", str(lst2), "-t", "unzip", "-o", str(udir), "-n", "3"])
+    assert r.returncode == 0, r.stderr
+    for stem, w in datas.items():
+        assert (udir / f"{stem}.mrc").read_bytes() == util.erase_expected(w, 8).tobytes()   # adapt.c:307-308
+    # throughput mode writes nothing (workers.c:39, -d 1)
+    tdir = tmp_path / "t"
+    tdir.mkdir()
+    r = _run([exe, "-i", str(lst), "-t", "zip", "-o", str(tdir), "-b", "8", "-n", "2", "-d", "1"])
+    assert r.returncode == 0 and all(os.path.getsize(tdir / f"{s}.mrc.zip") == 0 for s in datas)
+    bad = tmp_path / "bad.txt"
+    bad.write_text(str(srcdir / "x.dat") + "\n")
+    assert _run([exe, "-i", str(bad), "-t", "zip", "-o", str(zdir)]).returncode != 0     # adapt.c:309-311
+
+
+@pytest.mark.skipif(util.ref_binary("mrc_tar_c") is None, reason="oracle/_ref not present on this box")
+def test_cross_decode_with_the_reference_binary(tmp_path):
+    exe, ref = os.path.join(BIN, "mrc_tar"), util.ref_binary("mrc_tar_c")
+    w = util.gauss_words(400000, seed=77)
+    src, z1, z2, b1, b2 = (tmp_path / n for n in ("in.mrc", "gpu.zip", "ref.zip", "b1", "b2"))
+    src.write_bytes(w.tobytes())
+    assert _run([exe, "-i", str(src), "-o", str(z1), "-b", "10", "-t", "zip"]).returncode == 0
+    assert _run([ref, "-i", str(src), "-o", str(z2), "-b", "10", "-t", "zip"]).returncode == 0
+    assert z1.read_bytes() == z2.read_bytes()
+    assert _run([ref, "-i", str(z1), "-o", str(b1), "-t", "unzip"]).returncode == 0      # reference decodes GPU output
+    assert _run([exe, "-i", str(z2), "-o", str(b2), "-t", "unzip"]).returncode == 0      # GPU decodes reference output
+    assert b1.read_bytes() == b2.read_bytes() == util.erase_expected(w, 10).tobytes()
