@@ -87,7 +87,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from datacompressionfloat_amd import MrcZipCodec
+    from datacompressionfloat_amd import MrcZipCodec, shard
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,29 +112,15 @@ def main():
     gather_buf = None
 
     def gather_records(rec):
-        """final stream concatenation gather to rank 0 (RCCL send/recv; sizes via all_gather)"""
+        """final stream concatenation gather to rank 0 (datacompressionfloat_amd/shard.py: sizes via
+        all_gather, records via RCCL send/recv)"""
         nonlocal gather_buf
         if world == 1:
             return rec.numel()
-        sizes = torch.zeros(world, dtype=torch.int64, device=device)
-        mine = torch.tensor([rec.numel()], dtype=torch.int64, device=device)
-        dist.all_gather_into_tensor(sizes, mine)
-        sz = sizes.tolist()
-        if rank == 0:
-            tot = sum(sz)
-            if gather_buf is None or gather_buf.numel() < tot:
-                gather_buf = torch.empty(int(tot * 1.05) + 1024, dtype=torch.uint8, device=device)
-            gather_buf[: sz[0]].copy_(rec)
-            off = sz[0]
-            reqs = []
-            for r in range(1, world):
-                reqs.append(dist.irecv(gather_buf[off: off + sz[r]], src=r))
-                off += sz[r]
-            for q in reqs:
-                q.wait()
-            return tot
-        dist.send(rec, dst=0)
-        return rec.numel()
+        if rank == 0 and gather_buf is None:
+            gather_buf = torch.empty(int(cap * world * 0.75) + 1024, dtype=torch.uint8, device=device)
+        full, sizes = shard.gather_records(rec, dist, dst=0, out=gather_buf)
+        return sum(sizes)
 
     def step():
         rec, _ = codec.compress_device(words, args.bits, first_chunk, out=rec_buf)
