@@ -46,6 +46,14 @@ struct mrcz_ctx {
     uint64_t *h_result;    /* pinned host mirror */
     DecStream *dstreams;
     uint32_t *fallback;
+    Cand *cands;           /* block-start candidates, MAXCAND per stream */
+    uint32_t *ncand;       /* [ns] candidate counts, then [ns + 1] prefix, then job counter */
+    uint32_t *candbase;
+    BlkJob *jobs;
+    uint2 *rawlist;        /* signature survivors awaiting full header validation */
+    uint32_t rawcap;
+    uint32_t *njobs;
+    uint32_t *h_counts;    /* pinned: totals read back between the decode stages */
     unsigned long long *dbgphase; /* 8 counters per stream when phase profiling is on */
     int phase_profile;
     uint8_t *planes;       /* decode only, allocated lazily */
@@ -110,12 +118,22 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->result, 8);
     if (e == hipSuccess) e = dalloc(&ctx->dstreams, ns);
     if (e == hipSuccess) e = dalloc(&ctx->fallback, ns);
+    if (e == hipSuccess) e = dalloc(&ctx->cands, ns * MAXCAND);
+    if (e == hipSuccess) e = dalloc(&ctx->ncand, ns);
+    if (e == hipSuccess) e = dalloc(&ctx->candbase, ns + 1);
+    if (e == hipSuccess) e = dalloc(&ctx->jobs, ns * MAXCAND);
+    if (e == hipSuccess) e = dalloc(&ctx->njobs, 4);
+    ctx->rawcap = (uint32_t)(ns * 16384u);
+    if (e == hipSuccess) e = dalloc(&ctx->rawlist, ctx->rawcap);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counts, 4 * sizeof(uint32_t));
     if (e == hipSuccess) e = dalloc(&ctx->dbgphase, ns * 20);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     /* the parallel inflate keeps its window, tables and a 32 KiB output stage in LDS (> 64 KiB) */
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_inflate_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_blk_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_blk_write, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
     if (e != hipSuccess) {
         mrcz_destroy(ctx);
         return e == hipSuccess ? MRCZ_ENOMEM : MRCZ_ENOMEM;
@@ -132,7 +150,8 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     (void)hipFree(ctx->tsum); (void)hipFree(ctx->tinfo); (void)hipFree(ctx->sinfo); (void)hipFree(ctx->blkstart);
     (void)hipFree(ctx->slideq); (void)hipFree(ctx->pairhist); (void)hipFree(ctx->blkfreq); (void)hipFree(ctx->blkcode);
     (void)hipFree(ctx->blkhdr); (void)hipFree(ctx->meta); (void)hipFree(ctx->lay); (void)hipFree(ctx->pairbits);
-    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->dbgphase);
+    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobs); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->njobs);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts); (void)hipFree(ctx->dbgphase);
     (void)hipFree(ctx->planes);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -282,9 +301,37 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
         const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
         const uint64_t bfl = (nfloats - c0 * chk) < (uint64_t)nb * chk ? (nfloats - c0 * chk) : (uint64_t)nb * chk;
         LAUNCH("k_parse_records", k_parse_records, dim3(1), dim3(64), rec, len, bfl, chk, ctx->dstreams, ctx->result);
-        LAUNCH_S("k_inflate_par", k_inflate_par, dim3(4 * nb), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
-               ctx->phase_profile ? ctx->dbgphase : (unsigned long long *)NULL);
-        LAUNCH("k_inflate_seq", k_inflate, dim3(4 * nb), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
+        const uint32_t ns = 4 * nb;
+        HIPCHK(hipMemsetAsync(ctx->ncand, 0, ns * sizeof(uint32_t), ctx->stream), "memset ncand");
+        HIPCHK(hipMemsetAsync(ctx->njobs, 0, 4 * sizeof(uint32_t), ctx->stream), "memset njobs");
+        LAUNCH("k_raw_copy", k_raw_copy, dim3(ns, 8), dim3(PT), rec, ctx->dstreams, ctx->planes);
+        if (ctx->phase_profile) {
+            /* profiling vehicle: every stream through the sequential-chain kernel with phase counters */
+            HIPCHK(hipMemsetAsync(ctx->fallback, 0xff, ns * sizeof(uint32_t), ctx->stream), "memset fallback");
+        } else {
+            /* block-parallel path: find block starts, size every candidate block, close the chains, write */
+            LAUNCH("k_scan_candidates", k_scan_candidates, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(256), rec, len,
+                   ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 1, ctx->rawcap);
+            LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(256), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 1,
+                   ctx->rawcap, ctx->cands, ctx->ncand);
+            LAUNCH("k_cand_index", k_cand_index, dim3(1), dim3(256), ctx->ncand, ns, ctx->candbase);
+            HIPCHK(hipMemcpyAsync(ctx->h_counts, ctx->candbase + ns, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy ncand");
+            HIPCHK(hipStreamSynchronize(ctx->stream), "sync (candidates)");
+            const uint32_t total = ctx->h_counts[0];
+            if (total)
+                LAUNCH_S("k_blk_count", k_blk_count, dim3(total), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ns, ctx->candbase,
+                         ctx->cands, ctx->planes);
+            LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->jobs, ctx->njobs, ctx->fallback);
+            HIPCHK(hipMemcpyAsync(ctx->h_counts + 1, ctx->njobs, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy njobs");
+            HIPCHK(hipStreamSynchronize(ctx->stream), "sync (chains)");
+            const uint32_t njobs = ctx->h_counts[1];
+            if (njobs)
+                LAUNCH_S("k_blk_write", k_blk_write, dim3(njobs), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->jobs,
+                         ctx->fallback, ctx->planes);
+        }
+        LAUNCH_S("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
+                 ctx->fallback, ctx->phase_profile ? ctx->dbgphase : (unsigned long long *)NULL);
+        LAUNCH("k_inflate_seq", k_inflate, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
         LAUNCH("k_merge_planes", k_merge_planes, dim3(1024, nb), dim3(256), ctx->planes, bfl, chk, out + c0 * chk);
     }
     HIPCHK(hipMemcpyAsync(ctx->h_result, ctx->result, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");

@@ -63,6 +63,7 @@ struct ParShared {
     uint32_t cur;       /* bit position inside the payload */
     uint32_t op;        /* plane bytes produced */
     uint32_t last;      /* last byte produced (what a distance-1 match replicates) */
+    uint32_t haslit;    /* sh.last is valid (some byte has been produced) */
     uint32_t status;    /* 0 running, 1 done, 2 error, 3 needs the sequential decoder */
     uint32_t btype, bfinal, nlen, ndist;
     uint32_t flag;
@@ -338,6 +339,7 @@ struct SubResult {
 /* P3: count walk.  Decode tokens from window bit `start` until the position reaches `limit` (or
  * END_BLOCK), counting the plane bytes they produce.  Nearly every token is sized by the two fast
  * tables (token bits, produced bytes) with a single 12-bit lookup each. */
+template <bool TRACK_LAST>
 __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t start, uint32_t limit)
 {
     SubResult r;
@@ -355,6 +357,7 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
         if (t - 1u < (uint32_t)MAXTOK && n != 0xffffu) { /* 1 <= t <= MAXTOK, distance 1 */
             buf >>= t; nb -= (int)t; pos += t;
             r.nout += n;
+            if (TRACK_LAST && n == 1u) r.lastlit = 0x100u | ((uint32_t)sh.lit.lut[idx] & 0xffu);
             continue;
         }
         /* general path: long codes, END_BLOCK, other distances, errors */
@@ -365,6 +368,7 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
         buf >>= l; nb -= l; pos += (uint32_t)l;
         if (sym < 256u) {
             r.nout++;
+            if (TRACK_LAST) r.lastlit = 0x100u | sym;
         } else if (sym == 256u) {
             r.flags |= F_EOB;
             break;
@@ -457,7 +461,7 @@ __device__ __forceinline__ void walker_run(Walker &w, ParShared &sh, uint8_t *st
         }
     }
 }
-constexpr uint32_t STG_BYTES = 32768u;   /* output bytes staged per flush */
+constexpr uint32_t STG_BYTES = 16384u;   /* output bytes staged per flush (2 workgroups per CU fit in LDS) */
 
 /* exclusive prefix sum over the 1024 threads of the workgroup; *total = sum of all */
 __device__ __forceinline__ uint32_t block_excl_sum_pt(uint32_t v, uint32_t *wtot /* [16] shared */, uint32_t *total)
@@ -651,17 +655,24 @@ __device__ __forceinline__ void hdr_lengths_wave0(ParShared &sh, int lane, uint3
 #undef HPH
 }
 
-__global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ rec, uint64_t reclen,
-                                                    const DecStream *__restrict__ ds, uint8_t *__restrict__ planes,
-                                                    uint32_t *__restrict__ fallback,
-                                                    unsigned long long *__restrict__ dbg /* NULL, or 8 phase counters per stream */)
+struct StreamView {
+    const uint8_t *rec;   /* chunk records of the batch */
+    uint64_t reclen;
+    uint64_t payoff;      /* byte offset of this stream's payload in rec */
+    uint64_t paybit0;     /* payoff * 8 */
+    uint32_t paybits, paylen;
+    uint8_t *out;         /* plane buffer of this stream */
+    uint32_t n;           /* plane bytes of this stream */
+};
+__device__ __forceinline__ StreamView make_view(const uint8_t *rec, uint64_t reclen, const DecStream &d, uint8_t *out)
 {
-    HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
-    ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
-    uint8_t *stg = reinterpret_cast<uint8_t *>(dynsm) + ((sizeof(ParShared) + 15u) & ~(size_t)15u);
-    const int tid = threadIdx.x;
-    const uint32_t s = blockIdx.x;
-    /* optional phase counters live in LDS so that they cost no registers */
+    StreamView sv;
+    sv.rec = rec; sv.reclen = reclen; sv.payoff = d.payoff; sv.paybit0 = d.payoff * 8ull;
+    sv.paybits = d.paylen * 8u; sv.paylen = d.paylen; sv.out = out; sv.n = d.n;
+    return sv;
+}
+
+/* optional phase counters live in LDS so that they cost no registers */
 #define PHASE(i)                                                         \
     do {                                                                 \
         if (dbg && tid == 0) {                                           \
@@ -670,192 +681,173 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
             sh.tp = now_;                                                \
         }                                                                \
     } while (0)
-    const DecStream d = ds[s];
-    uint8_t *out = planes + (size_t)s * CHK;
-    if (tid == 0) fallback[s] = 0;
-    if (d.raw) {
-        /* RAW plane (zip.c:267-270): funnel-shifted dword copy from the (unaligned) payload */
-        const uint8_t *src = rec + d.payoff;
-        const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
-        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src - mis);
-        uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
-        uint32_t nw = d.n >> 2;
-        if (mis && nw) nw--; /* the funnel shift reads one dword ahead: keep it inside the payload */
-        const uint32_t shb = 8u * mis;
-        for (uint32_t i = tid; i < nw; i += PT) {
-            const uint32_t a = s32[i];
-            o32[i] = mis ? ((a >> shb) | (s32[i + 1] << (32u - shb))) : a;
-        }
-        for (uint32_t i = 4u * nw + tid; i < d.n; i += PT) out[i] = src[i];
-        return;
-    }
-    const uint64_t paybit0 = d.payoff * 8ull;
-    const uint32_t paybits = d.paylen * 8u;
-    if (tid == 0) { sh.cur = 0; sh.op = 0; sh.last = 0; sh.status = 0; }
-    __syncthreads();
 
-    if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
-    for (;;) {
-        /* ------------------------------------------------ block header ------------------------------------------------ */
-        if (sh.status != 0) break;
-        if (dbg && tid == 0) sh.acc[10]++;
-        const uint32_t cur = sh.cur;
-        if (sh.op >= d.n) { if (tid == 0) sh.status = 1; __syncthreads(); break; }
-        if (cur + 3u > paybits) { if (tid == 0) sh.status = 2; __syncthreads(); break; }
-        const uint32_t lead = stage_bits(sh.win, HDR_WORDS, rec, reclen, paybit0, cur);
-        if (tid < 19) sh.bl[tid] = 0;
+/* Decode ONE deflate block of a stream: it starts at payload bit sh.cur, its plane bytes go to
+ * sv.out + sh.op (WRITE) or are only counted (!WRITE).  On return sh.cur is the first bit after the
+ * block, sh.op has advanced by the bytes produced, sh.last/sh.haslit hold the last byte produced, and
+ * sh.status != 0 reports 1 = final block done, 2 = malformed / unsupported, 3 = needs the sequential
+ * general-distance decoder.  All PT threads call it together. */
+template <bool WRITE>
+__device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, const StreamView &sv, int tid, unsigned long long *dbg)
+{
+    const uint32_t cur = sh.cur;
+        if (cur + 3u > sv.paybits) { if (tid == 0) sh.status = 2; __syncthreads(); return; }
+    const uint32_t lead = stage_bits(sh.win, HDR_WORDS, sv.rec, sv.reclen, sv.paybit0, cur);
+    if (tid < 19) sh.bl[tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        LdsBits lb;
+        lb.w = sh.win;
+        lb.pos = lead;
+        const uint32_t hdr = lb_get(lb, 3);
+        sh.bfinal = hdr & 1u;
+        sh.btype = hdr >> 1;
+        if (sh.btype == 0) {
+            lb.pos = lead + (((cur + 3u + 7u) & ~7u) - cur); /* to the byte boundary */
+            const uint32_t l = lb_get(lb, 16), nl = lb_get(lb, 16);
+            if ((l ^ 0xffffu) != nl) sh.status = 2;
+            sh.nlen = l;
+        } else if (sh.btype == 1) {
+            sh.nlen = 288;
+            sh.ndist = 30;
+        } else if (sh.btype == 2) {
+            const uint32_t v = lb_get(lb, 14);
+            sh.nlen = (v & 31u) + 257u;
+            sh.ndist = ((v >> 5) & 31u) + 1u;
+            sh.ncode = (v >> 10) + 4u;
+            if (sh.nlen > 286u || sh.ndist > 30u) sh.status = 2;
+        } else sh.status = 2;
+        sh.cur = cur + (lb.pos - lead);
+        sh.hpos = lb.pos;
+    }
+    __syncthreads();
+    if (sh.status != 0) return;
+    if (sh.btype == 1) {
+        if (tid < 288) sh.lens[tid] = (uint8_t)static_llen(tid);
+        else if (tid < 318) sh.lens[tid] = 5;
+        __syncthreads();
+    } else if (sh.btype == 2) {
+        /* code-length code lengths: 3 bits each, in the RFC 1951 permuted order */
+        if ((uint32_t)tid < sh.ncode) {
+            const uint32_t p = sh.hpos + 3u * (uint32_t)tid;
+            const uint32_t i = p >> 5, shf = p & 31u;
+            const unsigned long long v = ((unsigned long long)sh.win[i] | ((unsigned long long)sh.win[i + 1] << 32)) >> shf;
+            sh.bl[k_bl_order(tid)] = (uint8_t)(v & 7u);
+        }
+        __syncthreads();
+        PHASE(12);
+        huff_build(sh.dist, sh.bl, 19, tid, sh.bllut, 7);
+        PHASE(13);
+        if (tid < 64) hdr_lengths_wave0(sh, tid, cur, lead, dbg != nullptr);
+        __syncthreads();
+        if (sh.status != 0) return;
+    }
+    if (sh.btype == 0) {
+        /* stored block: copy LEN bytes */
+        const uint32_t l = sh.nlen, op = sh.op;
+        const uint32_t byte0 = sh.cur >> 3;
+        if (op + l > sv.n || (uint64_t)byte0 + l > sv.paylen) { if (tid == 0) sh.status = 2; __syncthreads(); return; }
+        const uint8_t *src = sv.rec + sv.payoff + byte0;
+        if (WRITE) for (uint32_t i = tid; i < l; i += PT) sv.out[op + i] = src[i];
         __syncthreads();
         if (tid == 0) {
-            LdsBits lb;
-            lb.w = sh.win;
-            lb.pos = lead;
-            const uint32_t hdr = lb_get(lb, 3);
-            sh.bfinal = hdr & 1u;
-            sh.btype = hdr >> 1;
-            if (sh.btype == 0) {
-                lb.pos = lead + (((cur + 3u + 7u) & ~7u) - cur); /* to the byte boundary */
-                const uint32_t l = lb_get(lb, 16), nl = lb_get(lb, 16);
-                if ((l ^ 0xffffu) != nl) sh.status = 2;
-                sh.nlen = l;
-            } else if (sh.btype == 1) {
-                sh.nlen = 288;
-                sh.ndist = 30;
-            } else if (sh.btype == 2) {
-                const uint32_t v = lb_get(lb, 14);
-                sh.nlen = (v & 31u) + 257u;
-                sh.ndist = ((v >> 5) & 31u) + 1u;
-                sh.ncode = (v >> 10) + 4u;
-                if (sh.nlen > 286u || sh.ndist > 30u) sh.status = 2;
-            } else sh.status = 2;
-            sh.cur = cur + (lb.pos - lead);
-            sh.hpos = lb.pos;
+            if (l) { sh.last = src[l - 1]; sh.haslit = 1; }
+            sh.op = op + l;
+            sh.cur += 8u * l;
+            if (sh.bfinal) sh.status = 1;
         }
         __syncthreads();
-        if (sh.status != 0) break;
-        if (sh.btype == 1) {
-            if (tid < 288) sh.lens[tid] = (uint8_t)static_llen(tid);
-            else if (tid < 318) sh.lens[tid] = 5;
-            __syncthreads();
-        } else if (sh.btype == 2) {
-            /* code-length code lengths: 3 bits each, in the RFC 1951 permuted order */
-            if ((uint32_t)tid < sh.ncode) {
-                const uint32_t p = sh.hpos + 3u * (uint32_t)tid;
-                const uint32_t i = p >> 5, shf = p & 31u;
-                const unsigned long long v = ((unsigned long long)sh.win[i] | ((unsigned long long)sh.win[i + 1] << 32)) >> shf;
-                sh.bl[k_bl_order(tid)] = (uint8_t)(v & 7u);
-            }
-            __syncthreads();
-            PHASE(12);
-            huff_build(sh.dist, sh.bl, 19, tid, sh.bllut, 7);
-            PHASE(13);
-            if (tid < 64) hdr_lengths_wave0(sh, tid, cur, lead, dbg != nullptr);
-            __syncthreads();
-            if (sh.status != 0) break;
-        }
-        if (sh.btype == 0) {
-            /* stored block: copy LEN bytes */
-            const uint32_t l = sh.nlen, op = sh.op;
-            const uint32_t byte0 = sh.cur >> 3;
-            if (op + l > d.n || (uint64_t)byte0 + l > d.paylen) { if (tid == 0) sh.status = 2; __syncthreads(); break; }
-            const uint8_t *src = rec + d.payoff + byte0;
-            for (uint32_t i = tid; i < l; i += PT) out[op + i] = src[i];
-            __syncthreads();
-            if (tid == 0) {
-                if (l) sh.last = src[l - 1];
-                sh.op = op + l;
-                sh.cur += 8u * l;
-                if (sh.bfinal) sh.status = 1;
-            }
-            __syncthreads();
-            continue;
-        }
-        PHASE(14);
-        huff_build(sh.lit, sh.lens, (int)sh.nlen, tid, sh.lit.lut, LBITS);
-        PHASE(15);
-        huff_build(sh.dist, sh.lens + sh.nlen, (int)sh.ndist, tid, sh.dist.lut, DBITS);
-        PHASE(16);
-        for (int i = tid; i < (1 << LBITS); i += PT) {
-            uint32_t nby;
-            sh.tb[i] = (uint8_t)fast_token_entry(sh, (uint32_t)i, &nby);
-            sh.tn[i] = (uint16_t)nby;
-        }
-        /* longest token of this block: bounds the exit-function domain */
-        if (tid == 0) { sh.dmax = 0; sh.maxtok = 1; }
-        __syncthreads();
-        if ((uint32_t)tid < sh.ndist) {
-            const uint32_t dl = sh.lens[sh.nlen + tid];
-            if (dl) atomicMax(&sh.dmax, dl + ((uint32_t)tid < 4u ? 0u : ((uint32_t)tid >> 1) - 1u));
-        }
-        __syncthreads();
-        if ((uint32_t)tid < sh.nlen) {
-            const uint32_t ll = sh.lens[tid];
-            if (ll) atomicMax(&sh.maxtok, tid < 257 ? ll : ll + (uint32_t)len_extra_bits(tid - 257 < 29 ? tid - 257 : 0) + sh.dmax);
-        }
-        __syncthreads();
-        if (tid == 0 && sh.maxtok > (uint32_t)MAXTOK) sh.maxtok = MAXTOK;
-        __syncthreads();
+        return;
+    }
+    PHASE(14);
+    huff_build(sh.lit, sh.lens, (int)sh.nlen, tid, sh.lit.lut, LBITS);
+    PHASE(15);
+    huff_build(sh.dist, sh.lens + sh.nlen, (int)sh.ndist, tid, sh.dist.lut, DBITS);
+    PHASE(16);
+    for (int i = tid; i < (1 << LBITS); i += PT) {
+        uint32_t nby;
+        sh.tb[i] = (uint8_t)fast_token_entry(sh, (uint32_t)i, &nby);
+        sh.tn[i] = (uint16_t)nby;
+    }
+    /* longest token of this block: bounds the exit-function domain */
+    if (tid == 0) { sh.dmax = 0; sh.maxtok = 1; }
+    __syncthreads();
+    if ((uint32_t)tid < sh.ndist) {
+        const uint32_t dl = sh.lens[sh.nlen + tid];
+        if (dl) atomicMax(&sh.dmax, dl + ((uint32_t)tid < 4u ? 0u : ((uint32_t)tid >> 1) - 1u));
+    }
+    __syncthreads();
+    if ((uint32_t)tid < sh.nlen) {
+        const uint32_t ll = sh.lens[tid];
+        if (ll) atomicMax(&sh.maxtok, tid < 257 ? ll : ll + (uint32_t)len_extra_bits(tid - 257 < 29 ? tid - 257 : 0) + sh.dmax);
+    }
+    __syncthreads();
+    if (tid == 0 && sh.maxtok > (uint32_t)MAXTOK) sh.maxtok = MAXTOK;
+    __syncthreads();
 
-        PHASE(0);
-        /* ------------------------------------------------ block body, window by window ------------------------------------------------ */
-        for (;;) {
-            if (dbg && tid == 0) sh.acc[11]++;
-            const uint32_t wcur = sh.cur;
-            const uint32_t wlead = stage_bits(sh.win, WIN_WORDS, rec, reclen, paybit0, wcur);
-            __syncthreads();
-            PHASE(1);
-            const uint32_t pstart = wlead + (uint32_t)tid * SUBBITS;
-            const uint32_t limit = pstart + SUBBITS;
-            /* P1: exit function of my piece */
-            const ExitFn mine = piece_exit_fn(sh, pstart);
-            PHASE(2);
-            /* P2: inclusive Kogge-Stone scan of function composition across the wave */
-            ExitFn inc = mine;
-            {
-                const int l = lane_id();
-                for (int dd = 1; dd < 64; dd <<= 1) {
-                    ExitFn y;
-                    y.lo = __shfl_up(inc.lo, dd);
-                    y.hi = __shfl_up(inc.hi, dd);
-                    if (l >= dd) inc = fn_compose(y, inc);
-                }
-                if (l == 63) { sh.fnlo[tid >> 6] = inc.lo; sh.fnhi[tid >> 6] = inc.hi; }
+
+    PHASE(0);
+    /* ---------------- block body, window by window ---------------- */
+    for (;;) {
+        if (dbg && tid == 0) sh.acc[11]++;
+        const uint32_t wcur = sh.cur;
+        const uint32_t wlead = stage_bits(sh.win, WIN_WORDS, sv.rec, sv.reclen, sv.paybit0, wcur);
+        __syncthreads();
+        PHASE(1);
+        const uint32_t pstart = wlead + (uint32_t)tid * SUBBITS;
+        const uint32_t limit = pstart + SUBBITS;
+        /* P1: exit function of my piece */
+        const ExitFn mine = piece_exit_fn(sh, pstart);
+        PHASE(2);
+        /* P2: inclusive Kogge-Stone scan of function composition across the wave */
+        ExitFn inc = mine;
+        {
+            const int l = lane_id();
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                ExitFn y;
+                y.lo = __shfl_up(inc.lo, dd);
+                y.hi = __shfl_up(inc.hi, dd);
+                if (l >= dd) inc = fn_compose(y, inc);
             }
-            ExitFn exc; /* composition of the pieces before mine inside the wave */
-            exc.lo = __shfl_up(inc.lo, 1);
-            exc.hi = __shfl_up(inc.hi, 1);
+            if (l == 63) { sh.fnlo[tid >> 6] = inc.lo; sh.fnhi[tid >> 6] = inc.hi; }
+        }
+        ExitFn exc; /* composition of the pieces before mine inside the wave */
+        exc.lo = __shfl_up(inc.lo, 1);
+        exc.hi = __shfl_up(inc.hi, 1);
+        __syncthreads();
+        uint32_t entry = 0; /* the window is staged so that its first piece starts on a token */
+        for (int ww = 0; ww < (tid >> 6) && entry < (uint32_t)MAXTOK; ww++) {
+            ExitFn t;
+            t.lo = sh.fnlo[ww]; t.hi = sh.fnhi[ww];
+            entry = fn_get(t, entry);
+        }
+        if (lane_id() != 0 && entry < (uint32_t)MAXTOK) entry = fn_get(exc, entry);
+        __syncthreads();
+        const uint32_t start = entry < (uint32_t)MAXTOK ? pstart + entry : POS_INVALID;
+        PHASE(3);
+        /* P3: walk from the true entry, counting */
+        SubResult r;
+        if (start != POS_INVALID) r = count_walk<!WRITE>(sh, start, limit);
+        else { r.land = POS_INVALID; r.nout = 0; r.flags = (entry == X_ERR) ? F_ERR : 0; r.lastlit = 0; }
+        PHASE(4);
+        /* first lane that ended the block (or failed); lanes after it are inactive */
+        const uint32_t e = block_min_pt((r.flags & (F_EOB | F_ERR)) ? (uint32_t)tid : 0xffffffffu, sh.scan_a);
+        const bool active = start != POS_INVALID;
+        if (tid == 0) sh.flag = 0;
+        __syncthreads();
+        if (r.flags & (F_GENERAL | F_ERR)) sh.flag = r.flags | F_ERR;
+        __syncthreads();
+        const uint32_t bad_flags = sh.flag;
+        uint32_t total;
+        const uint32_t myoff = block_excl_sum_pt(active ? r.nout : 0u, sh.scan_a, &total);
+        PHASE(5);
+        const uint32_t op = sh.op;
+        if (bad_flags || op + total > sv.n) {
+            if (tid == 0) sh.status = (bad_flags & F_GENERAL) ? 3 : 2;
             __syncthreads();
-            uint32_t entry = 0; /* the window is staged so that its first piece starts on a token */
-            for (int ww = 0; ww < (tid >> 6) && entry < (uint32_t)MAXTOK; ww++) {
-                ExitFn t;
-                t.lo = sh.fnlo[ww]; t.hi = sh.fnhi[ww];
-                entry = fn_get(t, entry);
-            }
-            if (lane_id() != 0 && entry < (uint32_t)MAXTOK) entry = fn_get(exc, entry);
-            __syncthreads();
-            const uint32_t start = entry < (uint32_t)MAXTOK ? pstart + entry : POS_INVALID;
-            PHASE(3);
-            /* P3: walk from the true entry, counting */
-            SubResult r;
-            if (start != POS_INVALID) r = count_walk(sh, start, limit);
-            else { r.land = POS_INVALID; r.nout = 0; r.flags = (entry == X_ERR) ? F_ERR : 0; r.lastlit = 0; }
-            PHASE(4);
-            /* first lane that ended the block (or failed); lanes after it are inactive */
-            const uint32_t e = block_min_pt((r.flags & (F_EOB | F_ERR)) ? (uint32_t)tid : 0xffffffffu, sh.scan_a);
-            const bool active = start != POS_INVALID;
-            if (tid == 0) sh.flag = 0;
-            __syncthreads();
-            if (r.flags & (F_GENERAL | F_ERR)) sh.flag = r.flags | F_ERR;
-            __syncthreads();
-            const uint32_t bad_flags = sh.flag;
-            uint32_t total;
-            const uint32_t myoff = block_excl_sum_pt(active ? r.nout : 0u, sh.scan_a, &total);
-            PHASE(5);
-            const uint32_t op = sh.op;
-            if (bad_flags || op + total > d.n) {
-                if (tid == 0) sh.status = (bad_flags & F_GENERAL) ? 3 : 2;
-                __syncthreads();
-                break;
-            }
+            break;
+        }
+        if (WRITE) {
             {
                 Walker wk;
                 if (active && r.nout) walker_init(wk, sh, start, limit, myoff);
@@ -863,7 +855,7 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
                 uint32_t carry = sh.last; /* byte that precedes the segment */
                 for (uint32_t seg = 0; seg < total; seg += STG_BYTES) {
                     const uint32_t seg_hi = seg + STG_BYTES < total ? seg + STG_BYTES : total;
-                    uint8_t *dst = out + op + seg;
+                    uint8_t *dst = sv.out + op + seg;
                     const uint32_t lead = (uint32_t)((uintptr_t)dst & 15u);
                     sh.bitmap[tid] = 0; /* PT words x 32 = STG_BYTES positions */
                     __syncthreads();
@@ -880,7 +872,7 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
                         uint32_t v = inl ? (inl & 0xffu) : carry;
                         const uint32_t nvalid = seg_hi - seg;
                         if (32u * (uint32_t)tid < nvalid) {
-#pragma unroll 8
+    #pragma unroll 8
                             for (uint32_t i = 0; i < 32u; i++) {
                                 if ((word >> i) & 1u) v = q[i];
                                 else q[i] = (uint8_t)v;
@@ -905,31 +897,379 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
                     }
                     __syncthreads();
                 }
-                if (tid == 0 && total) sh.last = carry; /* last byte this window produced */
+                if (tid == 0 && total) { sh.last = carry; sh.haslit = 1; } /* last byte this window produced */
             }
-            if (tid == PT - 1) sh.op = op + total;
-            if (e != 0xffffffffu) {
-                if ((uint32_t)tid == e) {
-                    sh.cur = wcur + (r.land - wlead); /* r.land is just past END_BLOCK */
-                    if (sh.bfinal) sh.status = 1;
-                }
-            } else if (tid == PT - 1) {
-                sh.cur = wcur + (r.land - wlead);
+
+        } else {
+            /* count-only pass: remember the last literal (what a following block's leading match replicates) */
+            const uint32_t before = block_excl_last_pt(active ? r.lastlit : 0u, sh.scan_b);
+            if (tid == PT - 1) {
+                const uint32_t lw = (active && r.lastlit) ? r.lastlit : before;
+                if (lw) { sh.last = lw & 0xffu; sh.haslit = 1; }
             }
-            __syncthreads();
-            PHASE(8);
-            if (e != 0xffffffffu) break; /* next block */
-            if (sh.cur > paybits) { if (tid == 0) sh.status = 2; __syncthreads(); break; }
         }
+        if (tid == PT - 1) sh.op = op + total;
+        if (e != 0xffffffffu) {
+            if ((uint32_t)tid == e) {
+                sh.cur = wcur + (r.land - wlead); /* r.land is just past END_BLOCK */
+                if (sh.bfinal) sh.status = 1;
+            }
+        } else if (tid == PT - 1) {
+            sh.cur = wcur + (r.land - wlead);
+        }
+        __syncthreads();
+        PHASE(8);
+        if (e != 0xffffffffu) break; /* next block */
+        if (sh.cur > sv.paybits) { if (tid == 0) sh.status = 2; __syncthreads(); break; }
+    }
+}
+
+/* ======================================================================================
+ * kernels
+ * ==================================================================================== */
+constexpr int MAXCAND = 1024; /* block-start candidates kept per stream */
+struct Cand {
+    uint32_t bit;    /* payload bit where a block (seems to) start */
+    uint32_t end;    /* first bit after its END_BLOCK */
+    uint32_t nout;   /* plane bytes it produces */
+    uint32_t info;   /* bit 0 ok | bit 1 decoded | (0x100 | last byte) << 8 when it produced a literal */
+};
+struct BlkJob {
+    uint32_t stream, bit, off, inlast;
+};
+
+/* RAW planes (zip.c:267-270): funnel-shifted dword copy from the (unaligned) payload */
+__global__ __launch_bounds__(PT) void k_raw_copy(const uint8_t *__restrict__ rec, const DecStream *__restrict__ ds,
+                                                 uint8_t *__restrict__ planes)
+{
+    const int tid = threadIdx.x;
+    const uint32_t s = blockIdx.x;
+    const DecStream d = ds[s];
+    if (!d.raw) return;
+    uint8_t *out = planes + (size_t)s * CHK;
+    const uint8_t *src = rec + d.payoff;
+    const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src - mis);
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
+    uint32_t nw = d.n >> 2;
+    if (mis && nw) nw--; /* the funnel shift reads one dword ahead: keep it inside the payload */
+    const uint32_t shb = 8u * mis;
+    for (uint32_t i = blockIdx.y * PT + tid; i < nw; i += gridDim.y * PT) {
+        const uint32_t a = s32[i];
+        o32[i] = mis ? ((a >> shb) | (s32[i + 1] << (32u - shb))) : a;
+    }
+    if (blockIdx.y == 0)
+        for (uint32_t i = 4u * nw + tid; i < d.n; i += PT) out[i] = src[i];
+}
+
+/* D1: every bit position of every compressed payload is tested for the signature of a dynamic-block
+ * header as zlib writes it in Z_RLE streams: BFINAL=0, BTYPE=2, HLIT <= 29, HDIST == 1, and a complete
+ * code-length code (Kraft sum exactly 1).  Survivors are block-start CANDIDATES; correctness never
+ * depends on them (k_chain only accepts a candidate that the previous block's END_BLOCK lands on, and
+ * any stream whose chain cannot be closed is decoded sequentially instead). */
+constexpr int SLAB_BYTES = 32768;
+__global__ __launch_bounds__(256) void k_scan_candidates(const uint8_t *__restrict__ rec, uint64_t reclen,
+                                                         const DecStream *__restrict__ ds, Cand *__restrict__ cands,
+                                                         uint32_t *__restrict__ ncand, uint2 *__restrict__ rawlist,
+                                                         uint32_t *__restrict__ nraw, uint32_t rawcap)
+{
+    const uint32_t s = blockIdx.y;
+    const DecStream d = ds[s];
+    if (d.raw) return;
+    const uint32_t slab0 = blockIdx.x * SLAB_BYTES;
+    if (slab0 >= d.paylen) return;
+    const uint32_t paybits = d.paylen * 8u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { /* the first block always starts at bit 0 */
+        const uint32_t i = atomicAdd(&ncand[s], 1u);
+        if (i < (uint32_t)MAXCAND) { Cand c; c.bit = 0; c.end = 0; c.nout = 0; c.info = 0; cands[(size_t)s * MAXCAND + i] = c; }
+    }
+    const uint64_t gbyte0 = d.payoff + slab0;
+    /* dword-aligned view of the records */
+    const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
+    const uint64_t nrec32 = reclen >> 2;
+    const uint64_t gbit0 = gbyte0 * 8ull;
+    /* thread t scans 1024 consecutive bit positions */
+    const uint64_t tbit = gbit0 + 1024ull * threadIdx.x;
+    uint64_t wi = tbit >> 5;
+    uint32_t w0 = wi < nrec32 ? rec32[wi] : 0u, w1 = wi + 1 < nrec32 ? rec32[wi + 1] : 0u;
+    const uint32_t lead = (uint32_t)(tbit & 31u);
+    for (int k = 0; k < 33; k++) { /* 33 words cover lead + 1024 positions */
+        const uint32_t w2 = wi + 2 < nrec32 ? rec32[wi + 2] : 0u;
+        const unsigned long long win = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+        uint32_t hits = 0;
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+            const uint32_t v = (uint32_t)(win >> b);
+            /* bits 0..2 = 0b100 (BFINAL 0, BTYPE 2), bits 8..12 = HDIST == 1, HLIT = bits 3..7 <= 29 */
+            const bool hit = ((v & 0x1f07u) == 0x0104u) && (((v >> 3) & 31u) <= 29u);
+            hits |= (hit ? 1u : 0u) << b;
+        }
+        while (hits) {
+            const int b = __builtin_ctz(hits);
+            hits &= hits - 1u;
+            const uint64_t gp = (wi << 5) + (uint32_t)b;
+            if (gp < tbit || gp >= tbit + 1024ull) continue;
+            const uint64_t p64 = gp - d.payoff * 8ull;
+            if (p64 == 0 || p64 + 17u + 57u > paybits) continue;
+            const uint32_t p = (uint32_t)p64;
+            /* code-length code: HCLEN + 4 lengths of 3 bits after the 17 header bits */
+            const uint64_t q = gp + 13u;
+            const uint64_t qi = q >> 5;
+            const uint32_t a0 = qi < nrec32 ? rec32[qi] : 0u, a1 = qi + 1 < nrec32 ? rec32[qi + 1] : 0u;
+            const uint32_t a2 = qi + 2 < nrec32 ? rec32[qi + 2] : 0u;
+            const uint32_t sh0 = (uint32_t)(q & 31u);
+            const unsigned long long lo = ((unsigned long long)a0 | ((unsigned long long)a1 << 32)) >> sh0;
+            const unsigned long long hi = sh0 ? ((unsigned long long)a2 << (64u - sh0)) : 0ull;
+            unsigned long long bits = lo | hi;           /* 64 bits from q: HCLEN(4) then 3-bit lengths */
+            const uint32_t ncode = (uint32_t)(bits & 15u) + 4u;
+            bits >>= 4;
+            uint32_t kraft = 0, nz = 0;
+            for (uint32_t i = 0; i < ncode; i++) {
+                const uint32_t l = (uint32_t)(bits >> (3u * i)) & 7u;  /* 19 x 3 = 57 bits <= 60 available */
+                if (l) { kraft += 128u >> l; nz++; }
+            }
+            if (kraft != 128u || nz < 2u) continue;
+            const uint32_t i = atomicAdd(nraw, 1u);
+            if (i < rawcap) rawlist[i] = make_uint2(s, p); /* validated by k_validate_candidates */
+        }
+        (void)lead;
+        w0 = w1; w1 = w2; wi++;
+    }
+}
+
+/* D1b: one lane per signature survivor decodes the whole dynamic header sequentially (from HBM/L2)
+ * and keeps the candidate only if the header is fully consistent: the code lengths fill exactly
+ * HLIT + HDIST entries, END_BLOCK has a code, and the literal/length code is complete (Kraft sum exactly
+ * 1, as every tree zlib builds).  After this test false candidates are practically extinct. */
+__device__ __forceinline__ uint32_t gbits(const uint8_t *rec, uint64_t reclen, uint64_t bit, int n) /* n <= 16 */
+{
+    const uint64_t by = bit >> 3;
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++) if (by + k < reclen) v |= (uint32_t)rec[by + k] << (8 * k);
+    return (v >> (bit & 7u)) & ((1u << n) - 1u);
+}
+__global__ __launch_bounds__(256) void k_validate_candidates(const uint8_t *__restrict__ rec, uint64_t reclen,
+                                                             const DecStream *__restrict__ ds, const uint2 *__restrict__ rawlist,
+                                                             const uint32_t *__restrict__ nraw, uint32_t rawcap,
+                                                             Cand *__restrict__ cands, uint32_t *__restrict__ ncand)
+{
+    uint32_t total = *nraw;
+    if (total > rawcap) total = rawcap;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
+        const uint32_t s = rawlist[j].x, p = rawlist[j].y;
+        const DecStream d = ds[s];
+        const uint64_t g0 = d.payoff * 8ull + p;
+        const uint32_t paybits = d.paylen * 8u;
+        const uint32_t nlen = gbits(rec, reclen, g0 + 3, 5) + 257u, ndist = gbits(rec, reclen, g0 + 8, 5) + 1u;
+        const uint32_t ncode = gbits(rec, reclen, g0 + 13, 4) + 4u;
+        /* code-length code: canonical codes of <= 7 bits -> first-code/offset arrays in registers */
+        uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint8_t bl[19];
+        for (int i = 0; i < 19; i++) bl[i] = 0;
+        for (uint32_t i = 0; i < ncode; i++) {
+            const uint32_t l = gbits(rec, reclen, g0 + 17 + 3u * i, 3);
+            bl[k_bl_order((int)i)] = (uint8_t)l;
+            cnt[l]++;
+        }
+        cnt[0] = 0;
+        uint32_t first[8], offs[8], code = 0, idx0 = 0;
+        for (int l = 1; l <= 7; l++) { first[l] = code; offs[l] = idx0; code = (code + cnt[l]) << 1; idx0 += cnt[l]; }
+        uint8_t sorted[19];
+        {
+            uint32_t cur[8];
+            for (int l = 0; l < 8; l++) cur[l] = 0;
+            for (int i = 0; i < 19; i++) if (bl[i]) { sorted[offs[bl[i]] + cur[bl[i]]] = (uint8_t)i; cur[bl[i]]++; }
+        }
+        uint64_t pos = g0 + 17 + 3ull * ncode;
+        const uint32_t total_l = nlen + ndist;
+        uint32_t idx = 0, kraft = 0, prev = 0, eoblen = 0;
+        bool ok = nlen <= 286u && ndist <= 30u;
+        while (ok && idx < total_l) {
+            if (pos - d.payoff * 8ull + 14u > paybits) { ok = false; break; }
+            const uint32_t v = gbits(rec, reclen, pos, 14);
+            /* canonical decode, MSB-first code accumulation */
+            uint32_t c = 0;
+            int l = 0, sym = -1;
+            for (l = 1; l <= 7; l++) {
+                c = (c << 1) | ((v >> (l - 1)) & 1u);
+                if (c - first[l] < cnt[l]) { sym = sorted[offs[l] + (c - first[l])]; break; }
+            }
+            if (sym < 0) { ok = false; break; }
+            pos += (uint32_t)l;
+            uint32_t rep = 1, val = (uint32_t)sym;
+            if (sym == 16) { if (idx == 0) { ok = false; break; } val = prev; rep = 3u + ((v >> l) & 3u); pos += 2; }
+            else if (sym == 17) { val = 0; rep = 3u + ((v >> l) & 7u); pos += 3; }
+            else if (sym == 18) { val = 0; rep = 11u + ((v >> l) & 127u); pos += 7; }
+            if (idx + rep > total_l) { ok = false; break; }
+            for (uint32_t k = 0; k < rep; k++) {
+                const uint32_t at = idx + k;
+                if (at < nlen) { if (val) kraft += 32768u >> val; if (at == 256u) eoblen = val; }
+            }
+            idx += rep;
+            prev = val;
+        }
+        if (ok && kraft == 32768u && eoblen != 0u) {
+            const uint32_t i = atomicAdd(&ncand[s], 1u);
+            if (i < (uint32_t)MAXCAND) { Cand cnd; cnd.bit = p; cnd.end = 0; cnd.nout = 0; cnd.info = 0; cands[(size_t)s * MAXCAND + i] = cnd; }
+        }
+    }
+}
+
+/* exclusive prefix of the candidate counts -> job numbering for k_blk_count */
+__global__ __launch_bounds__(256) void k_cand_index(const uint32_t *__restrict__ ncand, uint32_t nstreams,
+                                                    uint32_t *__restrict__ candbase /* [nstreams + 1] */)
+{
+    if (threadIdx.x != 0) return;
+    uint32_t run = 0;
+    for (uint32_t s = 0; s < nstreams; s++) {
+        candbase[s] = run;
+        const uint32_t c = ncand[s];
+        run += c < (uint32_t)MAXCAND ? c : (uint32_t)MAXCAND;
+    }
+    candbase[nstreams] = run;
+}
+
+/* D2: decode every candidate block without writing: where does it end, how many plane bytes does it
+ * produce, what is its last byte */
+__global__ __launch_bounds__(PT) void k_blk_count(const uint8_t *__restrict__ rec, uint64_t reclen,
+                                                  const DecStream *__restrict__ ds, uint32_t nstreams,
+                                                  const uint32_t *__restrict__ candbase, Cand *__restrict__ cands,
+                                                  uint8_t *__restrict__ planes)
+{
+    HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
+    ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
+    uint8_t *stg = reinterpret_cast<uint8_t *>(dynsm) + ((sizeof(ParShared) + 15u) & ~(size_t)15u);
+    const int tid = threadIdx.x;
+    const uint32_t job = blockIdx.x;
+    uint32_t lo = 0, hi = nstreams - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (candbase[mid] <= job) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t s = lo, ci = job - candbase[lo];
+    Cand *c = &cands[(size_t)s * MAXCAND + ci];
+    const DecStream d = ds[s];
+    const StreamView sv = make_view(rec, reclen, d, planes + (size_t)s * CHK);
+    if (tid == 0) { sh.cur = c->bit; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
+    __syncthreads();
+    decode_one_block<false>(sh, stg, sv, tid, nullptr);
+    __syncthreads();
+    if (tid == 0) {
+        const bool ok = (sh.status == 0 || sh.status == 1) && sh.cur > c->bit;
+        c->end = sh.cur;
+        c->nout = sh.op;
+        c->info = (ok ? 1u : 0u) | 2u | (sh.haslit ? ((0x100u | (sh.last & 0xffu)) << 8) : 0u) | (sh.status == 1 ? 4u : 0u);
+    }
+}
+
+/* D3: follow the chain of blocks of every stream from bit 0: a block is accepted only where the
+ * previous one ended.  Emits one write job per block, or marks the stream for the sequential path. */
+__global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, uint64_t reclen,
+                                              const DecStream *__restrict__ ds, const Cand *__restrict__ cands,
+                                              const uint32_t *__restrict__ ncand, BlkJob *__restrict__ jobs,
+                                              uint32_t *__restrict__ njobs, uint32_t *__restrict__ fallback)
+{
+    const uint32_t s = blockIdx.x;
+    const DecStream d = ds[s];
+    const int lane = lane_id();
+    if (d.raw) { if (lane == 0) fallback[s] = 0; return; }
+    uint32_t nc = ncand[s];
+    bool fail = nc > (uint32_t)MAXCAND;
+    if (nc > (uint32_t)MAXCAND) nc = MAXCAND;
+    const Cand *cs = cands + (size_t)s * MAXCAND;
+    uint32_t pos = 0, off = 0, last = 0;
+    for (uint32_t step = 0; !fail && off < d.n && step < (uint32_t)MAXCAND; step++) {
+        /* the candidate that starts exactly at pos */
+        uint32_t found = 0xffffffffu;
+        for (uint32_t i0 = 0; i0 < nc; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool m = i < nc && cs[i].bit == pos && (cs[i].info & 1u);
+            const unsigned long long b = __ballot(m);
+            if (b) { found = i0 + (uint32_t)__builtin_ctzll(b); break; }
+        }
+        Cand c;
+        if (found == 0xffffffffu) {
+            /* no dynamic-header candidate here: zlib stores incompressible blocks (typically the first and
+             * the last block of a near-random plane); a stored block is sized from its LEN field directly */
+            const uint64_t g0 = d.payoff * 8ull + pos;
+            if (pos + 3u > d.paylen * 8u || gbits(rec, reclen, g0, 3) != 0u) { fail = true; break; } /* BFINAL 0, BTYPE 0 */
+            const uint32_t db = (pos + 3u + 7u) & ~7u; /* LEN, NLEN after the pad */
+            if ((uint64_t)db + 32u > (uint64_t)d.paylen * 8u) { fail = true; break; }
+            const uint32_t l = gbits(rec, reclen, d.payoff * 8ull + db, 16), nl = gbits(rec, reclen, d.payoff * 8ull + db + 16, 16);
+            if ((l ^ 0xffffu) != nl || (uint64_t)db + 32u + 8ull * l > (uint64_t)d.paylen * 8u) { fail = true; break; }
+            c.bit = pos; c.end = db + 32u + 8u * l; c.nout = l;
+            c.info = 3u | (l ? ((0x100u | (uint32_t)rec[d.payoff + (db >> 3) + 4u + l - 1u]) << 8) : 0u);
+            if (l == 0u && off < d.n && c.end >= d.paylen * 8u) { fail = true; break; } /* only the sync marker is left */
+        } else c = cs[found];
+        if (off + c.nout > d.n || c.end <= pos) { fail = true; break; }
+        if (lane == 0) {
+            const uint32_t j = atomicAdd(njobs, 1u);
+            BlkJob b;
+            b.stream = s; b.bit = pos; b.off = off; b.inlast = last;
+            jobs[j] = b;
+        }
+        off += c.nout;
+        if (c.info >> 8) last = (c.info >> 8) & 0xffu;
+        pos = c.end;
+        if ((c.info & 4u) && off < d.n) { fail = true; break; } /* a final block before the plane is complete */
+    }
+    if (!fail && off != d.n) fail = true;
+    if (lane == 0) fallback[s] = fail ? 1u : 0u; /* jobs of a failed stream are skipped by k_blk_write */
+}
+
+/* D4: decode the accepted blocks again, this time writing plane bytes at their final offsets */
+__global__ __launch_bounds__(PT) void k_blk_write(const uint8_t *__restrict__ rec, uint64_t reclen,
+                                                  const DecStream *__restrict__ ds, const BlkJob *__restrict__ jobs,
+                                                  const uint32_t *__restrict__ fallback, uint8_t *__restrict__ planes)
+{
+    HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
+    ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
+    uint8_t *stg = reinterpret_cast<uint8_t *>(dynsm) + ((sizeof(ParShared) + 15u) & ~(size_t)15u);
+    const int tid = threadIdx.x;
+    const BlkJob job = jobs[blockIdx.x];
+    if (fallback[job.stream]) return;
+    const DecStream d = ds[job.stream];
+    const StreamView sv = make_view(rec, reclen, d, planes + (size_t)job.stream * CHK);
+    if (tid == 0) { sh.cur = job.bit; sh.op = job.off; sh.last = job.inlast; sh.haslit = 0; sh.status = 0; }
+    __syncthreads();
+    decode_one_block<true>(sh, stg, sv, tid, nullptr);
+}
+
+/* Sequential-chain path (one workgroup walks all blocks of a stream): used for streams whose block
+ * chain could not be closed from the candidates (stored / static / final blocks, truncated input) and
+ * as the profiling vehicle of the per-block phases. */
+__global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ rec, uint64_t reclen,
+                                                    const DecStream *__restrict__ ds, uint8_t *__restrict__ planes,
+                                                    uint32_t *__restrict__ fallback, const uint32_t *__restrict__ only,
+                                                    unsigned long long *__restrict__ dbg /* NULL, or 20 phase counters per stream */)
+{
+    HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
+    ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
+    uint8_t *stg = reinterpret_cast<uint8_t *>(dynsm) + ((sizeof(ParShared) + 15u) & ~(size_t)15u);
+    const int tid = threadIdx.x;
+    const uint32_t s = blockIdx.x;
+    const DecStream d = ds[s];
+    if (d.raw) return;                  /* k_raw_copy */
+    if (only && only[s] == 0) return;   /* already decoded block-parallel */
+    const StreamView sv = make_view(rec, reclen, d, planes + (size_t)s * CHK);
+    if (tid == 0) { sh.cur = 0; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
+    __syncthreads();
+    if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
+    for (;;) {
+        if (sh.status != 0) break;
+        if (sh.op >= sv.n) { if (tid == 0) sh.status = 1; __syncthreads(); break; }
+        if (dbg && tid == 0) sh.acc[10]++;
+        decode_one_block<true>(sh, stg, sv, tid, dbg);
+        __syncthreads();
     }
     __syncthreads();
     if (tid == 0) {
-        if (sh.status == 1 && sh.op != d.n) sh.status = 2;
+        if (sh.status == 1 && sh.op != sv.n) sh.status = 2;
         /* 2 and 3 both hand the stream to the sequential decoder, which reports real format errors */
         fallback[s] = (sh.status == 1) ? 0u : 1u;
         if (dbg) for (int i = 0; i < 20; i++) dbg[(size_t)s * 20 + i] = sh.acc[i];
     }
-#undef PHASE
 }
+#undef PHASE
 
 } /* namespace mrcz */
