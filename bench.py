@@ -179,10 +179,25 @@ def main():
         dom = max(acc, key=acc.get)
         # algorithmic bytes of one launch: what the kernel must read once + write once
         alg = {"k_tile_summary": 4.0 * nfloats, "k_histogram": 4.0 * nfloats, "k_emit": 4.0 * nfloats + zbytes,
-               "k_inflate": zbytes + 4.0 * nfloats, "k_merge_planes": 8.0 * nfloats}.get(dom, 4.0 * nfloats + zbytes)
+               "k_inflate_par": zbytes + 1.0 * nfloats * 4, "k_blk_count": 1.0 * zbytes, "k_blk_write": zbytes + 4.0 * nfloats,
+               "k_blk_decode": zbytes + 4.0 * nfloats, "k_merge_planes": 8.0 * nfloats}.get(dom, 4.0 * nfloats + zbytes)
         achieved = alg / (acc[dom] * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if the
+        # dominant kernel has no committed measurement
+        traffic = None
+        try:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[::-1]:
+                k = json.load(open(f)).get("kernels", {}).get(dom)
+                if k:
+                    traffic = k["corrected_bytes"]
+                    break
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(acc[dom], 4),
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes": int(alg),
+                    "avg_launch_ms": round(acc[dom], 4),
                     "kernel_ms": {k: round(v, 4) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}}
         cpu = None
         if not args.no_cpu_baseline:

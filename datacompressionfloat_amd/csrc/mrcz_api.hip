@@ -50,6 +50,8 @@ struct mrcz_ctx {
     uint32_t *ncand;       /* [ns] candidate counts, then [ns + 1] prefix, then job counter */
     uint32_t *candbase;
     BlkJob *jobs;
+    uint8_t *ecache;       /* piece entries handed from k_blk_count to k_blk_write */
+    uint32_t ecache_rows;
     uint2 *rawlist;        /* signature survivors awaiting full header validation */
     uint32_t rawcap;
     uint32_t *njobs;
@@ -123,6 +125,8 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->candbase, ns + 1);
     if (e == hipSuccess) e = dalloc(&ctx->jobs, ns * MAXCAND);
     if (e == hipSuccess) e = dalloc(&ctx->njobs, 4);
+    ctx->ecache_rows = (uint32_t)(ns * (MAXBLK + MAXBLK / 4));
+    if (e == hipSuccess) e = dalloc(&ctx->ecache, (size_t)ctx->ecache_rows * ECACHE_WINDOWS * PT);
     ctx->rawcap = (uint32_t)(ns * 16384u);
     if (e == hipSuccess) e = dalloc(&ctx->rawlist, ctx->rawcap);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counts, 4 * sizeof(uint32_t));
@@ -150,7 +154,7 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     (void)hipFree(ctx->tsum); (void)hipFree(ctx->tinfo); (void)hipFree(ctx->sinfo); (void)hipFree(ctx->blkstart);
     (void)hipFree(ctx->slideq); (void)hipFree(ctx->pairhist); (void)hipFree(ctx->blkfreq); (void)hipFree(ctx->blkcode);
     (void)hipFree(ctx->blkhdr); (void)hipFree(ctx->meta); (void)hipFree(ctx->lay); (void)hipFree(ctx->pairbits);
-    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobs); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->njobs);
+    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobs); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->ecache); (void)hipFree(ctx->njobs);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts); (void)hipFree(ctx->dbgphase);
     (void)hipFree(ctx->planes);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
@@ -320,14 +324,14 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
             const uint32_t total = ctx->h_counts[0];
             if (total)
                 LAUNCH_S("k_blk_count", k_blk_count, dim3(total), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ns, ctx->candbase,
-                         ctx->cands, ctx->planes);
-            LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->jobs, ctx->njobs, ctx->fallback);
+                         ctx->cands, ctx->planes, ctx->ecache, ctx->ecache_rows);
+            LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->candbase, ctx->jobs, ctx->njobs, ctx->fallback);
             HIPCHK(hipMemcpyAsync(ctx->h_counts + 1, ctx->njobs, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy njobs");
             HIPCHK(hipStreamSynchronize(ctx->stream), "sync (chains)");
             const uint32_t njobs = ctx->h_counts[1];
             if (njobs)
                 LAUNCH_S("k_blk_write", k_blk_write, dim3(njobs), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->jobs,
-                         ctx->fallback, ctx->planes);
+                         ctx->fallback, ctx->planes, ctx->ecache, ctx->ecache_rows);
         }
         LAUNCH_S("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
                  ctx->fallback, ctx->phase_profile ? ctx->dbgphase : (unsigned long long *)NULL);

@@ -25,7 +25,7 @@
 
 namespace mrcz {
 
-constexpr int PT = 1024;                      /* threads per stream */
+constexpr int PT = 512;                       /* threads per workgroup (2 workgroups per CU: 128 VGPRs each) */
 constexpr int SUBBITS = 256;                  /* bits per lane piece */
 constexpr int WINBITS = PT * SUBBITS;         /* 32 KiB of compressed data per window */
 constexpr int MAXTOK = 24;                    /* longest token (bits) the parallel path resolves */
@@ -37,8 +37,9 @@ constexpr int DBITS = 10;                     /* index bits of the distance fast
 constexpr uint32_t POS_INVALID = 0xffffffffu;
 enum { F_EOB = 1, F_ERR = 2, F_GENERAL = 4 };
 
-struct HuffDec {
-    uint16_t lut[1 << LBITS]; /* sym | len << 9; 0 = code longer than the table's index bits (or unused) */
+template <int TB>
+struct HuffDecT {
+    uint16_t lut[1 << TB]; /* sym | len << 9; 0 = code longer than the table's index bits (or unused) */
     uint16_t limit[16];       /* left-justified (15-bit) upper bound of the codes of each length */
     uint16_t count[16];
     uint16_t first[16];
@@ -46,13 +47,17 @@ struct HuffDec {
     uint16_t sorted[320];
     uint16_t wcnt[5][16];     /* per-wave (64 symbols) count of each code length */
 };
+using HuffDec = HuffDecT<LBITS>;   /* literal/length code */
+using HuffDecD = HuffDecT<DBITS>;  /* distance code (also hosts the code-length code while a header is parsed) */
+
 
 struct ParShared {
     uint32_t win[WIN_WORDS];
     unsigned long long fnlo[PT / 64], fnhi[PT / 64]; /* exit function of each wave */
     uint32_t scan_a[PT / 64];
     uint32_t scan_b[PT / 64];
-    HuffDec lit, dist;
+    HuffDec lit;
+    HuffDecD dist;
     uint32_t bitmap[PT];      /* literal positions of the staged output segment */
     uint16_t bllut[128];      /* code-length code (<= 7 bits): sym | len << 9 */
     uint8_t tb[1 << LBITS];   /* token bits when the 12 index bits determine them, 0 = take the general path */
@@ -93,7 +98,8 @@ __device__ __forceinline__ uint32_t lb_get(LdsBits &b, int n)
 /* All PT threads (uniform control flow): canonical-code tables for `n` <= 320 code lengths.
  * Symbol t is owned by thread t; ranks among equal lengths come from wave ballots.  `lut` may be
  * h.lut (LBITS index bits) or a smaller table with `lutbits` index bits. */
-__device__ __forceinline__ void huff_build(HuffDec &h, const uint8_t *lens, int n, int tid, uint16_t *lut, int lutbits)
+template <class H>
+__device__ __forceinline__ void huff_build(H &h, const uint8_t *lens, int n, int tid, uint16_t *lut, int lutbits)
 {
     const int w = tid >> 6, l = tid & 63;
     const int mylen = tid < n ? lens[tid] : 0;
@@ -150,8 +156,8 @@ __device__ __forceinline__ void huff_build(HuffDec &h, const uint8_t *lens, int 
 /* decode one symbol from the low bits of v (>= 15 valid bits); returns sym | len << 16, or 0xffffffff.
  * Codes longer than the table's index bits are resolved by comparing the left-justified 15-bit
  * prefix against the per-length limits (canonical codes are ordered by length), not by a bit loop. */
-template <int TBITS>
-__device__ __forceinline__ uint32_t huff_decode_t(const HuffDec &h, uint32_t v)
+template <int TBITS, class H>
+__device__ __forceinline__ uint32_t huff_decode_t(const H &h, uint32_t v)
 {
     const uint32_t e = h.lut[v & ((1u << TBITS) - 1u)];
     if (e) return (e & 511u) | ((e >> 9) << 16);
@@ -165,7 +171,7 @@ __device__ __forceinline__ uint32_t huff_decode_t(const HuffDec &h, uint32_t v)
     return (uint32_t)h.sorted[h.offs[l] + d] | ((uint32_t)l << 16);
 }
 __device__ __forceinline__ uint32_t huff_decode(const HuffDec &h, uint32_t v) { return huff_decode_t<LBITS>(h, v); }
-__device__ __forceinline__ uint32_t huff_decode_dist(const HuffDec &h, uint32_t v) { return huff_decode_t<DBITS>(h, v); }
+__device__ __forceinline__ uint32_t huff_decode_dist(const HuffDecD &h, uint32_t v) { return huff_decode_t<DBITS>(h, v); }
 
 __device__ __forceinline__ uint32_t base_len_of(int lc) /* lc 0..28 -> match length base */
 {
@@ -655,6 +661,8 @@ __device__ __forceinline__ void hdr_lengths_wave0(ParShared &sh, int lane, uint3
 #undef HPH
 }
 
+constexpr int ECACHE_WINDOWS = 5; /* windows per block whose piece entries the count pass hands to the write pass */
+
 struct StreamView {
     const uint8_t *rec;   /* chunk records of the batch */
     uint64_t reclen;
@@ -688,8 +696,10 @@ __device__ __forceinline__ StreamView make_view(const uint8_t *rec, uint64_t rec
  * sh.status != 0 reports 1 = final block done, 2 = malformed / unsupported, 3 = needs the sequential
  * general-distance decoder.  All PT threads call it together. */
 template <bool WRITE>
-__device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, const StreamView &sv, int tid, unsigned long long *dbg)
+__device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, const StreamView &sv, int tid, unsigned long long *dbg,
+                                                 uint8_t *ecache /* NULL, or ECACHE_WINDOWS x PT piece entries of this block */)
 {
+    uint32_t widx = 0; /* window number inside the block */
     const uint32_t cur = sh.cur;
         if (cur + 3u > sv.paybits) { if (tid == 0) sh.status = 2; __syncthreads(); return; }
     const uint32_t lead = stage_bits(sh.win, HDR_WORDS, sv.rec, sv.reclen, sv.paybit0, cur);
@@ -796,33 +806,42 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
         PHASE(1);
         const uint32_t pstart = wlead + (uint32_t)tid * SUBBITS;
         const uint32_t limit = pstart + SUBBITS;
-        /* P1: exit function of my piece */
-        const ExitFn mine = piece_exit_fn(sh, pstart);
-        PHASE(2);
-        /* P2: inclusive Kogge-Stone scan of function composition across the wave */
-        ExitFn inc = mine;
-        {
-            const int l = lane_id();
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                ExitFn y;
-                y.lo = __shfl_up(inc.lo, dd);
-                y.hi = __shfl_up(inc.hi, dd);
-                if (l >= dd) inc = fn_compose(y, inc);
+        uint32_t entry;
+        const bool cached = WRITE && ecache != nullptr && widx < (uint32_t)ECACHE_WINDOWS;
+        if (cached) {
+            /* the count pass already resolved this window: entry offset of every piece, one byte each */
+            entry = ecache[(size_t)widx * PT + tid];
+        } else {
+            /* P1: exit function of my piece */
+            const ExitFn mine = piece_exit_fn(sh, pstart);
+            PHASE(2);
+            /* P2: inclusive Kogge-Stone scan of function composition across the wave */
+            ExitFn inc = mine;
+            {
+                const int l = lane_id();
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    ExitFn y;
+                    y.lo = __shfl_up(inc.lo, dd);
+                    y.hi = __shfl_up(inc.hi, dd);
+                    if (l >= dd) inc = fn_compose(y, inc);
+                }
+                if (l == 63) { sh.fnlo[tid >> 6] = inc.lo; sh.fnhi[tid >> 6] = inc.hi; }
             }
-            if (l == 63) { sh.fnlo[tid >> 6] = inc.lo; sh.fnhi[tid >> 6] = inc.hi; }
+            ExitFn exc; /* composition of the pieces before mine inside the wave */
+            exc.lo = __shfl_up(inc.lo, 1);
+            exc.hi = __shfl_up(inc.hi, 1);
+            __syncthreads();
+            entry = 0; /* the window is staged so that its first piece starts on a token */
+            for (int ww = 0; ww < (tid >> 6) && entry < (uint32_t)MAXTOK; ww++) {
+                ExitFn t;
+                t.lo = sh.fnlo[ww]; t.hi = sh.fnhi[ww];
+                entry = fn_get(t, entry);
+            }
+            if (lane_id() != 0 && entry < (uint32_t)MAXTOK) entry = fn_get(exc, entry);
+            __syncthreads();
+            if (!WRITE && ecache != nullptr && widx < (uint32_t)ECACHE_WINDOWS) ecache[(size_t)widx * PT + tid] = (uint8_t)entry;
         }
-        ExitFn exc; /* composition of the pieces before mine inside the wave */
-        exc.lo = __shfl_up(inc.lo, 1);
-        exc.hi = __shfl_up(inc.hi, 1);
-        __syncthreads();
-        uint32_t entry = 0; /* the window is staged so that its first piece starts on a token */
-        for (int ww = 0; ww < (tid >> 6) && entry < (uint32_t)MAXTOK; ww++) {
-            ExitFn t;
-            t.lo = sh.fnlo[ww]; t.hi = sh.fnhi[ww];
-            entry = fn_get(t, entry);
-        }
-        if (lane_id() != 0 && entry < (uint32_t)MAXTOK) entry = fn_get(exc, entry);
-        __syncthreads();
+        widx++;
         const uint32_t start = entry < (uint32_t)MAXTOK ? pstart + entry : POS_INVALID;
         PHASE(3);
         /* P3: walk from the true entry, counting */
@@ -936,6 +955,8 @@ struct Cand {
 };
 struct BlkJob {
     uint32_t stream, bit, off, inlast;
+    uint32_t cidx;   /* compact candidate index (row of the entry cache), 0xffffffff = none (stored block) */
+    uint32_t pad[3];
 };
 
 /* RAW planes (zip.c:267-270): funnel-shifted dword copy from the (unaligned) payload */
@@ -1134,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_cand_index(const uint32_t *__restrict__
 __global__ __launch_bounds__(PT) void k_blk_count(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                   const DecStream *__restrict__ ds, uint32_t nstreams,
                                                   const uint32_t *__restrict__ candbase, Cand *__restrict__ cands,
-                                                  uint8_t *__restrict__ planes)
+                                                  uint8_t *__restrict__ planes, uint8_t *__restrict__ ecache, uint32_t ecache_rows)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
     ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
@@ -1152,7 +1173,7 @@ __global__ __launch_bounds__(PT) void k_blk_count(const uint8_t *__restrict__ re
     const StreamView sv = make_view(rec, reclen, d, planes + (size_t)s * CHK);
     if (tid == 0) { sh.cur = c->bit; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
     __syncthreads();
-    decode_one_block<false>(sh, stg, sv, tid, nullptr);
+    decode_one_block<false>(sh, stg, sv, tid, nullptr, job < ecache_rows ? ecache + (size_t)job * ECACHE_WINDOWS * PT : nullptr);
     __syncthreads();
     if (tid == 0) {
         const bool ok = (sh.status == 0 || sh.status == 1) && sh.cur > c->bit;
@@ -1166,7 +1187,8 @@ __global__ __launch_bounds__(PT) void k_blk_count(const uint8_t *__restrict__ re
  * previous one ended.  Emits one write job per block, or marks the stream for the sequential path. */
 __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, uint64_t reclen,
                                               const DecStream *__restrict__ ds, const Cand *__restrict__ cands,
-                                              const uint32_t *__restrict__ ncand, BlkJob *__restrict__ jobs,
+                                              const uint32_t *__restrict__ ncand, const uint32_t *__restrict__ candbase,
+                                              BlkJob *__restrict__ jobs,
                                               uint32_t *__restrict__ njobs, uint32_t *__restrict__ fallback)
 {
     const uint32_t s = blockIdx.x;
@@ -1206,6 +1228,8 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
             const uint32_t j = atomicAdd(njobs, 1u);
             BlkJob b;
             b.stream = s; b.bit = pos; b.off = off; b.inlast = last;
+            b.cidx = found == 0xffffffffu ? 0xffffffffu : candbase[s] + found;
+            b.pad[0] = b.pad[1] = b.pad[2] = 0;
             jobs[j] = b;
         }
         off += c.nout;
@@ -1220,7 +1244,8 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
 /* D4: decode the accepted blocks again, this time writing plane bytes at their final offsets */
 __global__ __launch_bounds__(PT) void k_blk_write(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                   const DecStream *__restrict__ ds, const BlkJob *__restrict__ jobs,
-                                                  const uint32_t *__restrict__ fallback, uint8_t *__restrict__ planes)
+                                                  const uint32_t *__restrict__ fallback, uint8_t *__restrict__ planes,
+                                                  uint8_t *__restrict__ ecache, uint32_t ecache_rows)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
     ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
@@ -1232,7 +1257,7 @@ __global__ __launch_bounds__(PT) void k_blk_write(const uint8_t *__restrict__ re
     const StreamView sv = make_view(rec, reclen, d, planes + (size_t)job.stream * CHK);
     if (tid == 0) { sh.cur = job.bit; sh.op = job.off; sh.last = job.inlast; sh.haslit = 0; sh.status = 0; }
     __syncthreads();
-    decode_one_block<true>(sh, stg, sv, tid, nullptr);
+    decode_one_block<true>(sh, stg, sv, tid, nullptr, job.cidx < ecache_rows ? ecache + (size_t)job.cidx * ECACHE_WINDOWS * PT : nullptr);
 }
 
 /* Sequential-chain path (one workgroup walks all blocks of a stream): used for streams whose block
@@ -1259,7 +1284,7 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
         if (sh.status != 0) break;
         if (sh.op >= sv.n) { if (tid == 0) sh.status = 1; __syncthreads(); break; }
         if (dbg && tid == 0) sh.acc[10]++;
-        decode_one_block<true>(sh, stg, sv, tid, dbg);
+        decode_one_block<true>(sh, stg, sv, tid, dbg, nullptr);
         __syncthreads();
     }
     __syncthreads();
