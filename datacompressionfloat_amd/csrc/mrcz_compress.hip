@@ -364,15 +364,17 @@ __global__ __launch_bounds__(256) void k_histogram(const uint32_t *__restrict__ 
             const int q = select64(S, (int)(nextBnd - base));
             inA = (1ull << q) - 1ull;
         }
-        /* literals */
+        /* literals: unrolled over the lane's 64 positions (bytes come from registers), so the LDS
+         * atomics are issued back to back instead of one dependent ctz / load / atomic chain per symbol */
         {
-            uint64_t m = S & ~M;
-            const uint8_t *row = plane + lane * ROWPAD;
-            while (m) {
-                const int i = ctz64(m);
-                m &= m - 1;
-                uint32_t *r = ((inA >> i) & 1ull) ? rowA : rowB;
-                atomicAdd(&r[row[i]], 1u);
+            const uint64_t L = S & ~M;
+#pragma unroll
+            for (int i = 0; i < 64; i++) {
+                if ((L >> i) & 1ull) {
+                    const uint32_t byte = (x[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                    uint32_t *r = ((inA >> i) & 1ull) ? rowA : rowB;
+                    atomicAdd(&r[byte], 1u);
+                }
             }
         }
         /* matches */
@@ -722,7 +724,6 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t *__restrict__ in, u
         stage_tile(cin, t0, (uint32_t)len, mask, unmasked, lds);
         __syncthreads();
         const uint8_t *plane = lds + w * PLANE_LDS;
-        const uint8_t *row = plane + lane * ROWPAD;
         const TileInfo tinf = tinfo[(size_t)s * TPS + (t0 / TILE)];
         uint32_t x[16];
         lane_row(plane, lane, x);
@@ -785,13 +786,53 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t *__restrict__ in, u
             const uint64_t S = bytes_mode ? pm : (cls.S & pm);
             const uint64_t M = bytes_mode ? 0ull : (cls.M & pm);
 
-            /* pass A: bits produced by this lane */
+            if (bytes_mode) {
+                /* RAW plane / STORED block: plane bytes [pos0, pos1) go out verbatim at a byte-aligned
+                 * address.  The wave assembles aligned output dwords straight from the LDS plane tile
+                 * (4 byte reads each); only a partial first / last dword is merged with atomicOr. */
+                const uint32_t nbytes = (uint32_t)(pos1 - pos0);
+                const uint64_t dg = si.payoff + (cur >> 3);       /* cur is a multiple of 8 here */
+                const uint32_t mis = (uint32_t)(dg & 3u);
+                const uint64_t w0 = dg >> 2;
+                const uint32_t nwords = (mis + nbytes + 3u) >> 2;
+                for (uint32_t k = lane; k < nwords; k += 64) {
+                    uint32_t v = 0;
+                    bool full = true;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int rel = (int)(4u * k + (uint32_t)j) - (int)mis; /* byte of the part */
+                        if (rel >= 0 && rel < (int)nbytes) {
+                            const uint32_t pp = (uint32_t)pos0 + (uint32_t)rel;
+                            v |= (uint32_t)plane[(pp >> 6) * ROWPAD + (pp & 63u)] << (8 * j);
+                        } else full = false;
+                    }
+                    if (full) out32[w0 + k] = v;
+                    else if (v) atomicOr(&out32[w0 + k], v);
+                }
+                cur += 8u * nbytes;
+                pos0 = pos1;
+                continue;
+            }
+
+            /* pass A: bits produced by this lane.  The 64 table reads are independent (unrolled, bytes
+             * come from registers), so their LDS latency overlaps; matches are rare and handled apart. */
             uint32_t lbits = 0;
-            if (bytes_mode) lbits = 8u * (uint32_t)popc64(S);
-            else {
-                uint64_t m = S & ~M;
-                while (m) { const int i = ctz64(m); m &= m - 1; lbits += lut[row[i]] >> 16; }
-                m = M;
+            {
+                const uint64_t L = S & ~M;
+                const uint4 *row128 = reinterpret_cast<const uint4 *>(plane + lane * ROWPAD);
+#pragma unroll 1
+                for (int g = 0; g < 4; g++) { /* 16 positions per step: bounded register use, 16 reads in flight */
+                    const uint4 rw = row128[g];
+                    const uint32_t wv[4] = {rw.x, rw.y, rw.z, rw.w};
+                    const uint32_t Lg = (uint32_t)(L >> (16 * g)) & 0xffffu;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const uint32_t byte = (wv[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                        const uint32_t e = lut[byte];
+                        lbits += ((Lg >> j) & 1u) ? (e >> 16) : 0u;
+                    }
+                }
+                uint64_t m = M;
                 while (m) {
                     const int i = ctz64(m); m &= m - 1;
                     int xb, xv;
@@ -811,19 +852,27 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t *__restrict__ in, u
                 LanePacker pk;
                 packer_init(pk, stage, lead + lofs);
                 {
-                    uint64_t m = S;
-                    while (m) {
-                        const int i = ctz64(m);
-                        m &= m - 1;
-                        if ((M >> i) & 1ull) {
-                            int xb, xv;
-                            const int code = len_code(match_len_at(lt.E, lt.a, lt.nextS, i), &xb, &xv);
-                            const uint32_t e = lut[257 + code];
-                            const int cl = (int)(e >> 16);
-                            packer_put(pk, (e & 0xffffu) | ((uint32_t)xv << cl), cl + xb + (int)dbits);
-                        } else {
-                            const uint32_t e = lut[row[i]];
-                            packer_put(pk, e & 0xffffu, (int)(e >> 16));
+                    const uint4 *row128 = reinterpret_cast<const uint4 *>(plane + lane * ROWPAD);
+#pragma unroll 1
+                    for (int g = 0; g < 4; g++) {
+                        const uint4 rw = row128[g];
+                        const uint32_t wv[4] = {rw.x, rw.y, rw.z, rw.w};
+                        const uint32_t Sg = (uint32_t)(S >> (16 * g)) & 0xffffu, Mg = (uint32_t)(M >> (16 * g)) & 0xffffu;
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const uint32_t byte = (wv[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                            uint32_t e = lut[byte];
+                            uint32_t val = e & 0xffffu;
+                            int nb = (int)(e >> 16);
+                            if ((Mg >> j) & 1u) {
+                                int xb, xv;
+                                const int code = len_code(match_len_at(lt.E, lt.a, lt.nextS, 16 * g + j), &xb, &xv);
+                                e = lut[257 + code];
+                                const int cl = (int)(e >> 16);
+                                val = (e & 0xffffu) | ((uint32_t)xv << cl);
+                                nb = cl + xb + (int)dbits;
+                            }
+                            if ((Sg >> j) & 1u) packer_put(pk, val, nb);
                         }
                     }
                 }
