@@ -126,11 +126,11 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->jobs, ns * MAXCAND);
     if (e == hipSuccess) e = dalloc(&ctx->njobs, 4);
     ctx->ecache_rows = (uint32_t)(ns * (MAXBLK + MAXBLK / 4));
-    if (e == hipSuccess) e = dalloc(&ctx->ecache, (size_t)ctx->ecache_rows * ECACHE_WINDOWS * PT);
+    if (e == hipSuccess) e = dalloc(&ctx->ecache, (size_t)ctx->ecache_rows * ECACHE_ROW);
     ctx->rawcap = (uint32_t)(ns * 16384u);
     if (e == hipSuccess) e = dalloc(&ctx->rawlist, ctx->rawcap);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counts, 4 * sizeof(uint32_t));
-    if (e == hipSuccess) e = dalloc(&ctx->dbgphase, ns * 20);
+    if (e == hipSuccess) e = dalloc(&ctx->dbgphase, ns * 40);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
@@ -308,8 +308,9 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
         const uint32_t ns = 4 * nb;
         HIPCHK(hipMemsetAsync(ctx->ncand, 0, ns * sizeof(uint32_t), ctx->stream), "memset ncand");
         HIPCHK(hipMemsetAsync(ctx->njobs, 0, 4 * sizeof(uint32_t), ctx->stream), "memset njobs");
+        if (ctx->phase_profile == 2) HIPCHK(hipMemsetAsync(ctx->dbgphase, 0, (size_t)ns * 40 * sizeof(unsigned long long), ctx->stream), "memset dbg");
         LAUNCH("k_raw_copy", k_raw_copy, dim3(ns, 8), dim3(PT), rec, ctx->dstreams, ctx->planes);
-        if (ctx->phase_profile) {
+        if (ctx->phase_profile == 1) {
             /* profiling vehicle: every stream through the sequential-chain kernel with phase counters */
             HIPCHK(hipMemsetAsync(ctx->fallback, 0xff, ns * sizeof(uint32_t), ctx->stream), "memset fallback");
         } else {
@@ -324,17 +325,19 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
             const uint32_t total = ctx->h_counts[0];
             if (total)
                 LAUNCH_S("k_blk_count", k_blk_count, dim3(total), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ns, ctx->candbase,
-                         ctx->cands, ctx->planes, ctx->ecache, ctx->ecache_rows);
+                         ctx->cands, ctx->planes, ctx->ecache, ctx->ecache_rows,
+                         ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL);
             LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->candbase, ctx->jobs, ctx->njobs, ctx->fallback);
             HIPCHK(hipMemcpyAsync(ctx->h_counts + 1, ctx->njobs, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy njobs");
             HIPCHK(hipStreamSynchronize(ctx->stream), "sync (chains)");
             const uint32_t njobs = ctx->h_counts[1];
             if (njobs)
                 LAUNCH_S("k_blk_write", k_blk_write, dim3(njobs), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->jobs,
-                         ctx->fallback, ctx->planes, ctx->ecache, ctx->ecache_rows);
+                         ctx->fallback, ctx->planes, ctx->ecache, ctx->ecache_rows,
+                         ctx->phase_profile == 2 ? ctx->dbgphase + (size_t)4 * ctx->max_chunks * 20 : (unsigned long long *)NULL);
         }
         LAUNCH_S("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
-                 ctx->fallback, ctx->phase_profile ? ctx->dbgphase : (unsigned long long *)NULL);
+                 ctx->fallback, ctx->phase_profile == 1 ? ctx->dbgphase : (unsigned long long *)NULL);
         LAUNCH("k_inflate_seq", k_inflate, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
         LAUNCH("k_merge_planes", k_merge_planes, dim3(1024, nb), dim3(256), ctx->planes, bfl, chk, out + c0 * chk);
     }
@@ -412,7 +415,7 @@ extern "C" int mrcz_debug_inflate_phases(mrcz_ctx_t *ctx, int enable, uint32_t s
     if (!ctx) return MRCZ_EINVAL;
     ctx->phase_profile = enable;
     if (out) {
-        if (stream >= 4u * ctx->max_chunks) return MRCZ_EINVAL;
+        if (stream >= 8u * ctx->max_chunks) return MRCZ_EINVAL;
         if (hipMemcpy(out, ctx->dbgphase + (size_t)stream * 20, 20 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return MRCZ_EHIP;
     }
     return MRCZ_OK;

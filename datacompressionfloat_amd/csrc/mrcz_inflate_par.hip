@@ -467,6 +467,64 @@ __device__ __forceinline__ void walker_run(Walker &w, ParShared &sh, uint8_t *st
         }
     }
 }
+/* `n` copies of byte b at p (a distance-1 match): short runs byte by byte, long runs with 16-byte
+ * aligned stores */
+__device__ __forceinline__ void fill_global(uint8_t *p, uint32_t b, uint32_t n)
+{
+    if (n < 32u) {
+        for (uint32_t k = 0; k < n; k++) p[k] = (uint8_t)b;
+        return;
+    }
+    uint32_t k = 0;
+    while ((uintptr_t)(p + k) & 15u) p[k++] = (uint8_t)b;
+    const uint32_t w = 0x01010101u * b;
+    const uint4 v = make_uint4(w, w, w, w);
+    for (; k + 16u <= n; k += 16u) *reinterpret_cast<uint4 *>(p + k) = v;
+    for (; k < n; k++) p[k] = (uint8_t)b;
+}
+
+/* P4 walk of one lane: decode its piece from `start` and write the plane bytes at `out` */
+__device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, uint32_t limit, uint8_t *out, uint32_t last)
+{
+    uint32_t pos = start;
+    uint32_t wi = pos >> 5;
+    uint64_t buf = ((uint64_t)sh.win[wi] | ((uint64_t)sh.win[wi + 1] << 32)) >> (pos & 31u);
+    int nb = 64 - (int)(pos & 31u);
+    wi += 2;
+    while (pos < limit) {
+        if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
+        const uint32_t idx = (uint32_t)buf & ((1u << LBITS) - 1u);
+        const uint32_t t = sh.tb[idx];
+        const uint32_t n = sh.tn[idx];
+        if (t - 1u < (uint32_t)MAXTOK && n != 0xffffu) {
+            if (n == 1u) { last = (uint32_t)sh.lit.lut[idx] & 0xffu; *out++ = (uint8_t)last; }
+            else { fill_global(out, last, n); out += n; }
+            buf >>= t; nb -= (int)t; pos += t;
+            continue;
+        }
+        const uint32_t d = huff_decode(sh.lit, (uint32_t)buf);
+        if (d == 0xffffffffu) break;
+        const int l = (int)(d >> 16);
+        const uint32_t sym = d & 0xffffu;
+        buf >>= l; nb -= l; pos += (uint32_t)l;
+        if (sym < 256u) { last = sym; *out++ = (uint8_t)sym; }
+        else if (sym == 256u) break;
+        else {
+            const int lc = (int)sym - 257;
+            const int xb = len_extra_bits(lc);
+            const uint32_t ml = base_len_of(lc) + ((uint32_t)buf & ((1u << xb) - 1u));
+            buf >>= xb; nb -= xb; pos += (uint32_t)xb;
+            if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
+            const uint32_t dd = huff_decode_dist(sh.dist, (uint32_t)buf);
+            const int dl = (int)(dd >> 16), dc = (int)(dd & 0xffffu);
+            const int dxb = dc < 4 ? 0 : (dc >> 1) - 1;
+            buf >>= (dl + dxb); nb -= dl + dxb; pos += (uint32_t)(dl + dxb);
+            fill_global(out, last, ml);
+            out += ml;
+        }
+    }
+}
+
 constexpr uint32_t STG_BYTES = 16384u;   /* output bytes staged per flush (2 workgroups per CU fit in LDS) */
 
 /* exclusive prefix sum over the 1024 threads of the workgroup; *total = sum of all */
@@ -661,7 +719,13 @@ __device__ __forceinline__ void hdr_lengths_wave0(ParShared &sh, int lane, uint3
 #undef HPH
 }
 
+struct HdrCache {
+    uint32_t valid, bfinal, nlen, ndist, cur_after, pad[3];
+    uint8_t lens[320];
+};
 constexpr int ECACHE_WINDOWS = 5; /* windows per block whose piece entries the count pass hands to the write pass */
+
+constexpr size_t ECACHE_ROW = (size_t)ECACHE_WINDOWS * PT + sizeof(HdrCache); /* bytes per candidate */
 
 struct StreamView {
     const uint8_t *rec;   /* chunk records of the batch */
@@ -700,57 +764,72 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
                                                  uint8_t *ecache /* NULL, or ECACHE_WINDOWS x PT piece entries of this block */)
 {
     uint32_t widx = 0; /* window number inside the block */
-    const uint32_t cur = sh.cur;
-        if (cur + 3u > sv.paybits) { if (tid == 0) sh.status = 2; __syncthreads(); return; }
-    const uint32_t lead = stage_bits(sh.win, HDR_WORDS, sv.rec, sv.reclen, sv.paybit0, cur);
-    if (tid < 19) sh.bl[tid] = 0;
-    __syncthreads();
-    if (tid == 0) {
-        LdsBits lb;
-        lb.w = sh.win;
-        lb.pos = lead;
-        const uint32_t hdr = lb_get(lb, 3);
-        sh.bfinal = hdr & 1u;
-        sh.btype = hdr >> 1;
-        if (sh.btype == 0) {
-            lb.pos = lead + (((cur + 3u + 7u) & ~7u) - cur); /* to the byte boundary */
-            const uint32_t l = lb_get(lb, 16), nl = lb_get(lb, 16);
-            if ((l ^ 0xffffu) != nl) sh.status = 2;
-            sh.nlen = l;
-        } else if (sh.btype == 1) {
-            sh.nlen = 288;
-            sh.ndist = 30;
-        } else if (sh.btype == 2) {
-            const uint32_t v = lb_get(lb, 14);
-            sh.nlen = (v & 31u) + 257u;
-            sh.ndist = ((v >> 5) & 31u) + 1u;
-            sh.ncode = (v >> 10) + 4u;
-            if (sh.nlen > 286u || sh.ndist > 30u) sh.status = 2;
-        } else sh.status = 2;
-        sh.cur = cur + (lb.pos - lead);
-        sh.hpos = lb.pos;
-    }
-    __syncthreads();
-    if (sh.status != 0) return;
-    if (sh.btype == 1) {
-        if (tid < 288) sh.lens[tid] = (uint8_t)static_llen(tid);
-        else if (tid < 318) sh.lens[tid] = 5;
+    /* header cache: the count pass of a dynamic block hands its decoded code lengths to the write pass */
+    HdrCache *hc = ecache ? reinterpret_cast<HdrCache *>(ecache + (size_t)ECACHE_WINDOWS * PT) : nullptr;
+    const bool hdr_cached = WRITE && hc != nullptr && hc->valid == 0x600dcafeu;
+    if (hdr_cached) {
+        if (tid == 0) { sh.btype = 2; sh.bfinal = hc->bfinal; sh.nlen = hc->nlen; sh.ndist = hc->ndist; sh.cur = hc->cur_after; }
+        if (tid < 320) sh.lens[tid] = hc->lens[tid];
         __syncthreads();
-    } else if (sh.btype == 2) {
-        /* code-length code lengths: 3 bits each, in the RFC 1951 permuted order */
-        if ((uint32_t)tid < sh.ncode) {
-            const uint32_t p = sh.hpos + 3u * (uint32_t)tid;
-            const uint32_t i = p >> 5, shf = p & 31u;
-            const unsigned long long v = ((unsigned long long)sh.win[i] | ((unsigned long long)sh.win[i + 1] << 32)) >> shf;
-            sh.bl[k_bl_order(tid)] = (uint8_t)(v & 7u);
+    } else {
+        const uint32_t cur = sh.cur;
+            if (cur + 3u > sv.paybits) { if (tid == 0) sh.status = 2; __syncthreads(); return; }
+        const uint32_t lead = stage_bits(sh.win, HDR_WORDS, sv.rec, sv.reclen, sv.paybit0, cur);
+        if (tid < 19) sh.bl[tid] = 0;
+        __syncthreads();
+        if (tid == 0) {
+            LdsBits lb;
+            lb.w = sh.win;
+            lb.pos = lead;
+            const uint32_t hdr = lb_get(lb, 3);
+            sh.bfinal = hdr & 1u;
+            sh.btype = hdr >> 1;
+            if (sh.btype == 0) {
+                lb.pos = lead + (((cur + 3u + 7u) & ~7u) - cur); /* to the byte boundary */
+                const uint32_t l = lb_get(lb, 16), nl = lb_get(lb, 16);
+                if ((l ^ 0xffffu) != nl) sh.status = 2;
+                sh.nlen = l;
+            } else if (sh.btype == 1) {
+                sh.nlen = 288;
+                sh.ndist = 30;
+            } else if (sh.btype == 2) {
+                const uint32_t v = lb_get(lb, 14);
+                sh.nlen = (v & 31u) + 257u;
+                sh.ndist = ((v >> 5) & 31u) + 1u;
+                sh.ncode = (v >> 10) + 4u;
+                if (sh.nlen > 286u || sh.ndist > 30u) sh.status = 2;
+            } else sh.status = 2;
+            sh.cur = cur + (lb.pos - lead);
+            sh.hpos = lb.pos;
         }
         __syncthreads();
-        PHASE(12);
-        huff_build(sh.dist, sh.bl, 19, tid, sh.bllut, 7);
-        PHASE(13);
-        if (tid < 64) hdr_lengths_wave0(sh, tid, cur, lead, dbg != nullptr);
-        __syncthreads();
         if (sh.status != 0) return;
+        if (sh.btype == 1) {
+            if (tid < 288) sh.lens[tid] = (uint8_t)static_llen(tid);
+            else if (tid < 318) sh.lens[tid] = 5;
+            __syncthreads();
+        } else if (sh.btype == 2) {
+            /* code-length code lengths: 3 bits each, in the RFC 1951 permuted order */
+            if ((uint32_t)tid < sh.ncode) {
+                const uint32_t p = sh.hpos + 3u * (uint32_t)tid;
+                const uint32_t i = p >> 5, shf = p & 31u;
+                const unsigned long long v = ((unsigned long long)sh.win[i] | ((unsigned long long)sh.win[i + 1] << 32)) >> shf;
+                sh.bl[k_bl_order(tid)] = (uint8_t)(v & 7u);
+            }
+            __syncthreads();
+            PHASE(12);
+            huff_build(sh.dist, sh.bl, 19, tid, sh.bllut, 7);
+            PHASE(13);
+            if (tid < 64) hdr_lengths_wave0(sh, tid, cur, lead, dbg != nullptr);
+            __syncthreads();
+            if (sh.status != 0) return;
+        }
+        if (!WRITE && hc != nullptr) {
+            if (sh.btype == 2) {
+                if (tid < 320) hc->lens[tid] = sh.lens[tid];
+                if (tid == 0) { hc->bfinal = sh.bfinal; hc->nlen = sh.nlen; hc->ndist = sh.ndist; hc->cur_after = sh.cur; hc->valid = 0x600dcafeu; }
+            } else if (tid == 0) hc->valid = 0;
+        }
     }
     if (sh.btype == 0) {
         /* stored block: copy LEN bytes */
@@ -846,7 +925,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
         PHASE(3);
         /* P3: walk from the true entry, counting */
         SubResult r;
-        if (start != POS_INVALID) r = count_walk<!WRITE>(sh, start, limit);
+        if (start != POS_INVALID) r = count_walk<true>(sh, start, limit);
         else { r.land = POS_INVALID; r.nout = 0; r.flags = (entry == X_ERR) ? F_ERR : 0; r.lastlit = 0; }
         PHASE(4);
         /* first lane that ended the block (or failed); lanes after it are inactive */
@@ -867,58 +946,18 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
             break;
         }
         if (WRITE) {
-            {
-                Walker wk;
-                if (active && r.nout) walker_init(wk, sh, start, limit, myoff);
-                else { wk.buf = 0; wk.pos = 0; wk.limit = 0; wk.wi = 0; wk.nb = 0; wk.done = 1; wk.off = 0; }
-                uint32_t carry = sh.last; /* byte that precedes the segment */
-                for (uint32_t seg = 0; seg < total; seg += STG_BYTES) {
-                    const uint32_t seg_hi = seg + STG_BYTES < total ? seg + STG_BYTES : total;
-                    uint8_t *dst = sv.out + op + seg;
-                    const uint32_t lead = (uint32_t)((uintptr_t)dst & 15u);
-                    sh.bitmap[tid] = 0; /* PT words x 32 = STG_BYTES positions */
-                    __syncthreads();
-                    if (!wk.done && wk.off < seg_hi) walker_run(wk, sh, stg + lead, seg, seg_hi);
-                    PHASE(6);
-                    __syncthreads();
-                    PHASE(7);
-                    /* forward fill: thread t owns positions [32t, 32t+32) of the segment */
-                    {
-                        const uint32_t word = sh.bitmap[tid];
-                        uint8_t *q = stg + lead + 32u * (uint32_t)tid;
-                        const uint32_t mylast = word ? (0x100u | q[31 - __builtin_clz(word)]) : 0u;
-                        const uint32_t inl = block_excl_last_pt(mylast, sh.scan_b);
-                        uint32_t v = inl ? (inl & 0xffu) : carry;
-                        const uint32_t nvalid = seg_hi - seg;
-                        if (32u * (uint32_t)tid < nvalid) {
-    #pragma unroll 8
-                            for (uint32_t i = 0; i < 32u; i++) {
-                                if ((word >> i) & 1u) v = q[i];
-                                else q[i] = (uint8_t)v;
-                            }
-                        }
-                        /* byte preceding the next segment = value after the last valid position */
-                        if (tid == PT - 1) sh.flag = word ? (mylast & 0xffu) : (inl ? (inl & 0xffu) : carry);
-                    }
-                    __syncthreads();
-                    carry = sh.flag;
-                    /* flush: stage byte i <-> dst[i - lead]; 16-byte units, partial first/last unit by bytes */
-                    const uint32_t nb = seg_hi - seg;
-                    const uint32_t nunits = (lead + nb + 15u) >> 4;
-                    for (uint32_t u = tid; u < nunits; u += PT) {
-                        const uint32_t lo = 16u * u, hi = lo + 16u;
-                        if (lo >= lead && hi <= lead + nb) {
-                            *reinterpret_cast<uint4 *>(dst - lead + lo) = *reinterpret_cast<const uint4 *>(stg + lo);
-                        } else {
-                            const uint32_t a0 = lo < lead ? lead : lo, a1 = hi > lead + nb ? lead + nb : hi;
-                            for (uint32_t i = a0; i < a1; i++) dst[i - lead] = stg[i];
-                        }
-                    }
-                    __syncthreads();
-                }
-                if (tid == 0 && total) { sh.last = carry; sh.haslit = 1; } /* last byte this window produced */
+            /* P4: every lane walks its piece once more and writes its plane bytes straight to HBM: literals
+             * as bytes, distance-1 matches as fills of the last literal (wide aligned stores for long runs).
+             * A lane's output range is contiguous, lanes are independent, nothing is staged. */
+            const uint32_t lastin = sh.last; /* read before the scan's barriers: thread PT-1 rewrites it below */
+            const uint32_t before = block_excl_last_pt(active ? r.lastlit : 0u, sh.scan_b);
+            if (active && r.nout) write_walk(sh, start, limit, sv.out + op + myoff, before ? (before & 0xffu) : lastin);
+            PHASE(6);
+            if (tid == PT - 1) {
+                const uint32_t lw = (active && r.lastlit) ? r.lastlit : before;
+                if (lw) { sh.last = lw & 0xffu; sh.haslit = 1; }
             }
-
+            (void)stg;
         } else {
             /* count-only pass: remember the last literal (what a following block's leading match replicates) */
             const uint32_t before = block_excl_last_pt(active ? r.lastlit : 0u, sh.scan_b);
@@ -1155,7 +1194,8 @@ __global__ __launch_bounds__(256) void k_cand_index(const uint32_t *__restrict__
 __global__ __launch_bounds__(PT) void k_blk_count(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                   const DecStream *__restrict__ ds, uint32_t nstreams,
                                                   const uint32_t *__restrict__ candbase, Cand *__restrict__ cands,
-                                                  uint8_t *__restrict__ planes, uint8_t *__restrict__ ecache, uint32_t ecache_rows)
+                                                  uint8_t *__restrict__ planes, uint8_t *__restrict__ ecache, uint32_t ecache_rows,
+                                                  unsigned long long *__restrict__ dbg)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
     ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
@@ -1172,13 +1212,15 @@ __global__ __launch_bounds__(PT) void k_blk_count(const uint8_t *__restrict__ re
     const DecStream d = ds[s];
     const StreamView sv = make_view(rec, reclen, d, planes + (size_t)s * CHK);
     if (tid == 0) { sh.cur = c->bit; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
+    if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
     __syncthreads();
-    decode_one_block<false>(sh, stg, sv, tid, nullptr, job < ecache_rows ? ecache + (size_t)job * ECACHE_WINDOWS * PT : nullptr);
+    decode_one_block<false>(sh, stg, sv, tid, dbg, job < ecache_rows ? ecache + (size_t)job * ECACHE_ROW : nullptr);
     __syncthreads();
     if (tid == 0) {
         const bool ok = (sh.status == 0 || sh.status == 1) && sh.cur > c->bit;
         c->end = sh.cur;
         c->nout = sh.op;
+        if (dbg) for (int i = 0; i < 20; i++) atomicAdd(&dbg[(size_t)s * 20 + i], sh.acc[i]);
         c->info = (ok ? 1u : 0u) | 2u | (sh.haslit ? ((0x100u | (sh.last & 0xffu)) << 8) : 0u) | (sh.status == 1 ? 4u : 0u);
     }
 }
@@ -1245,7 +1287,7 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
 __global__ __launch_bounds__(PT) void k_blk_write(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                   const DecStream *__restrict__ ds, const BlkJob *__restrict__ jobs,
                                                   const uint32_t *__restrict__ fallback, uint8_t *__restrict__ planes,
-                                                  uint8_t *__restrict__ ecache, uint32_t ecache_rows)
+                                                  uint8_t *__restrict__ ecache, uint32_t ecache_rows, unsigned long long *__restrict__ dbg)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
     ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
@@ -1256,8 +1298,11 @@ __global__ __launch_bounds__(PT) void k_blk_write(const uint8_t *__restrict__ re
     const DecStream d = ds[job.stream];
     const StreamView sv = make_view(rec, reclen, d, planes + (size_t)job.stream * CHK);
     if (tid == 0) { sh.cur = job.bit; sh.op = job.off; sh.last = job.inlast; sh.haslit = 0; sh.status = 0; }
+    if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
     __syncthreads();
-    decode_one_block<true>(sh, stg, sv, tid, nullptr, job.cidx < ecache_rows ? ecache + (size_t)job.cidx * ECACHE_WINDOWS * PT : nullptr);
+    decode_one_block<true>(sh, stg, sv, tid, dbg, job.cidx < ecache_rows ? ecache + (size_t)job.cidx * ECACHE_ROW : nullptr);
+    __syncthreads();
+    if (dbg && tid == 0) for (int i = 0; i < 20; i++) atomicAdd(&dbg[(size_t)job.stream * 20 + i], sh.acc[i]);
 }
 
 /* Sequential-chain path (one workgroup walks all blocks of a stream): used for streams whose block

@@ -10,12 +10,14 @@ x = torch.empty(n, dtype=torch.float32, device="cuda").normal_(10.0, 3.0, genera
 c = MrcZipCodec(0, 16)
 rec, _ = c.compress_device(x, 8, 1)
 _LIB.mrcz_debug_inflate_phases.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
-_LIB.mrcz_debug_inflate_phases(c._ctx, 1, 0, None)
+import sys as _s
+MODE = int(_s.argv[1]) if len(_s.argv) > 1 else 1   # 1 = sequential-chain kernel, 2 = block-parallel kernels (count rows, then write rows)
+_LIB.mrcz_debug_inflate_phases(c._ctx, MODE, 0, None)
 out, _ = c.uncompress_device(rec, n)
 names = ["hdr", "stage", "P1 exitfn", "P2 compose", "P3 walk", "P3 scans", "P4 scatter", "P4 wait", "fill+flush", "-"]
-for s in (4, 5, 6, 7):
+for s in ((4, 5, 6, 7) if MODE == 1 else (6, 7, 64 + 6, 64 + 7)):
     buf = (ctypes.c_uint64 * 20)()
-    _LIB.mrcz_debug_inflate_phases(c._ctx, 1, s, buf)
+    _LIB.mrcz_debug_inflate_phases(c._ctx, MODE, s, buf)
     v = list(buf)
     tot = sum(v[:10]) + sum(v[12:20])
     print(f"stream {s} (plane {s % 4}): blocks={v[10]} windows={v[11]} total={tot / 1e8:.2f} ms@100MHz " +
