@@ -58,7 +58,6 @@ struct ParShared {
     uint32_t scan_b[PT / 64];
     HuffDec lit;
     HuffDecD dist;
-    uint32_t bitmap[PT];      /* literal positions of the staged output segment */
     uint16_t bllut[128];      /* code-length code (<= 7 bits): sym | len << 9 */
     uint8_t tb[1 << LBITS];   /* token bits when the 12 index bits determine them, 0 = take the general path */
     uint16_t tn[1 << LBITS];  /* plane bytes that token produces (1 literal, 3..258 match); 0xffff = not distance 1 */
@@ -400,73 +399,6 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
     return r;
 }
 
-/* P4: resumable write walk.  Plane bytes are staged in LDS (segment [seg_lo, seg_hi) of the window's
- * output) and flushed to HBM with coalesced 16-byte stores by the whole workgroup: per-lane byte or
- * dword stores scatter over 64 cache lines per wave instruction and were the slowest phase. */
-struct Walker {
-    uint64_t buf;
-    uint32_t pos, limit, wi;
-    int nb;
-    uint32_t off;    /* window-relative output offset of the next byte */
-    uint32_t done;
-};
-__device__ __forceinline__ void walker_init(Walker &w, const ParShared &sh, uint32_t start, uint32_t limit, uint32_t off)
-{
-    w.pos = start; w.limit = limit; w.off = off; w.done = 0;
-    w.wi = start >> 5;
-    w.buf = ((uint64_t)sh.win[w.wi] | ((uint64_t)sh.win[w.wi + 1] << 32)) >> (start & 31u);
-    w.nb = 64 - (int)(start & 31u);
-    w.wi += 2;
-}
-/* distance-1 matches replicate the previous byte, so the plane is fully defined by its literals:
- * lanes only scatter literal bytes (and mark them in a bitmap); a uniform forward fill then expands
- * the runs without any per-lane variable-length loop. */
-__device__ __forceinline__ void walker_run(Walker &w, ParShared &sh, uint8_t *stg /* stg[0] <-> offset seg_lo */,
-                                           uint32_t seg_lo, uint32_t seg_hi)
-{
-    while (!w.done && w.off < seg_hi) {
-        if (w.pos >= w.limit) { w.done = 1; break; }
-        if (w.nb < 32) { w.buf |= (uint64_t)sh.win[w.wi++] << w.nb; w.nb += 32; }
-        {
-            const uint32_t idx = (uint32_t)w.buf & ((1u << LBITS) - 1u);
-            const uint32_t t = sh.tb[idx];
-            const uint32_t n = sh.tn[idx];
-            if (t - 1u < (uint32_t)MAXTOK && n != 0xffffu) {
-                if (n == 1u) { /* literal */
-                    const uint32_t rel = w.off - seg_lo;
-                    stg[rel] = (uint8_t)sh.lit.lut[idx];
-                    atomicOr(&sh.bitmap[rel >> 5], 1u << (rel & 31u));
-                }
-                w.buf >>= t; w.nb -= (int)t; w.pos += t;
-                w.off += n;
-                continue;
-            }
-        }
-        const uint32_t d = huff_decode(sh.lit, (uint32_t)w.buf);
-        if (d == 0xffffffffu) { w.done = 1; break; }
-        const int l = (int)(d >> 16);
-        const uint32_t sym = d & 0xffffu;
-        w.buf >>= l; w.nb -= l; w.pos += (uint32_t)l;
-        if (sym < 256u) {
-            const uint32_t rel = w.off - seg_lo;
-            stg[rel] = (uint8_t)sym;
-            atomicOr(&sh.bitmap[rel >> 5], 1u << (rel & 31u));
-            w.off++;
-        } else if (sym == 256u) {
-            w.done = 1;
-        } else {
-            const int lc = (int)sym - 257;
-            const int xb = len_extra_bits(lc);
-            w.off += base_len_of(lc) + ((uint32_t)w.buf & ((1u << xb) - 1u));
-            w.buf >>= xb; w.nb -= xb; w.pos += (uint32_t)xb;
-            if (w.nb < 32) { w.buf |= (uint64_t)sh.win[w.wi++] << w.nb; w.nb += 32; }
-            const uint32_t dd = huff_decode_dist(sh.dist, (uint32_t)w.buf);
-            const int dl = (int)(dd >> 16), dc = (int)(dd & 0xffffu);
-            const int dxb = dc < 4 ? 0 : (dc >> 1) - 1;
-            w.buf >>= (dl + dxb); w.nb -= dl + dxb; w.pos += (uint32_t)(dl + dxb);
-        }
-    }
-}
 /* `n` copies of byte b at p (a distance-1 match): short runs byte by byte, long runs with 16-byte
  * aligned stores */
 __device__ __forceinline__ void fill_global(uint8_t *p, uint32_t b, uint32_t n)
@@ -525,7 +457,6 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
     }
 }
 
-constexpr uint32_t STG_BYTES = 16384u;   /* output bytes staged per flush (2 workgroups per CU fit in LDS) */
 
 /* exclusive prefix sum over the 1024 threads of the workgroup; *total = sum of all */
 __device__ __forceinline__ uint32_t block_excl_sum_pt(uint32_t v, uint32_t *wtot /* [16] shared */, uint32_t *total)
@@ -957,7 +888,6 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
                 const uint32_t lw = (active && r.lastlit) ? r.lastlit : before;
                 if (lw) { sh.last = lw & 0xffu; sh.haslit = 1; }
             }
-            (void)stg;
         } else {
             /* count-only pass: remember the last literal (what a following block's leading match replicates) */
             const uint32_t before = block_excl_last_pt(active ? r.lastlit : 0u, sh.scan_b);
@@ -1048,27 +978,24 @@ __global__ __launch_bounds__(256) void k_scan_candidates(const uint8_t *__restri
     const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
     const uint64_t nrec32 = reclen >> 2;
     const uint64_t gbit0 = gbyte0 * 8ull;
-    /* thread t scans 1024 consecutive bit positions */
-    const uint64_t tbit = gbit0 + 1024ull * threadIdx.x;
-    uint64_t wi = tbit >> 5;
-    uint32_t w0 = wi < nrec32 ? rec32[wi] : 0u, w1 = wi + 1 < nrec32 ? rec32[wi + 1] : 0u;
-    const uint32_t lead = (uint32_t)(tbit & 31u);
-    for (int k = 0; k < 33; k++) { /* 33 words cover lead + 1024 positions */
-        const uint32_t w2 = wi + 2 < nrec32 ? rec32[wi + 2] : 0u;
+    /* coalesced: in step k the 256 threads test the 32 positions starting in 256 consecutive dwords */
+    const uint64_t w_first = gbit0 >> 5;           /* gbyte0 may be unaligned: positions are global bits */
+    const uint64_t bit_lo = gbit0, bit_hi = gbit0 + 8ull * SLAB_BYTES;
+    for (int k = 0; k < SLAB_BYTES / 4 / 256 + 1; k++) {
+        const uint64_t wi = w_first + (uint64_t)k * 256u + threadIdx.x;
+        const uint32_t w0 = wi < nrec32 ? rec32[wi] : 0u, w1 = wi + 1 < nrec32 ? rec32[wi + 1] : 0u;
         const unsigned long long win = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
-        uint32_t hits = 0;
-#pragma unroll
-        for (int b = 0; b < 32; b++) {
-            const uint32_t v = (uint32_t)(win >> b);
-            /* bits 0..2 = 0b100 (BFINAL 0, BTYPE 2), bits 8..12 = HDIST == 1, HLIT = bits 3..7 <= 29 */
-            const bool hit = ((v & 0x1f07u) == 0x0104u) && (((v >> 3) & 31u) <= 29u);
-            hits |= (hit ? 1u : 0u) << b;
-        }
+        /* bit-parallel signature test of the 32 positions that start in word wi:
+         *   bits 0..2 = 0,0,1 (BFINAL 0, BTYPE 2)   bits 8..12 = 1,0,0,0,0 (HDIST == 1)
+         *   HLIT = bits 3..7 <= 29  <=>  not (bits 4,5,6,7 all set) */
+        const unsigned long long sig = ~win & ~(win >> 1) & (win >> 2) & (win >> 8) & ~(win >> 9) & ~(win >> 10) & ~(win >> 11) &
+                                       ~(win >> 12) & ~((win >> 4) & (win >> 5) & (win >> 6) & (win >> 7));
+        uint32_t hits = (uint32_t)sig;
         while (hits) {
             const int b = __builtin_ctz(hits);
             hits &= hits - 1u;
             const uint64_t gp = (wi << 5) + (uint32_t)b;
-            if (gp < tbit || gp >= tbit + 1024ull) continue;
+            if (gp < bit_lo || gp >= bit_hi) continue;
             const uint64_t p64 = gp - d.payoff * 8ull;
             if (p64 == 0 || p64 + 17u + 57u > paybits) continue;
             const uint32_t p = (uint32_t)p64;
@@ -1092,8 +1019,6 @@ __global__ __launch_bounds__(256) void k_scan_candidates(const uint8_t *__restri
             const uint32_t i = atomicAdd(nraw, 1u);
             if (i < rawcap) rawlist[i] = make_uint2(s, p); /* validated by k_validate_candidates */
         }
-        (void)lead;
-        w0 = w1; w1 = w2; wi++;
     }
 }
 
