@@ -73,6 +73,7 @@ struct ParShared {
     uint32_t flag;
     unsigned long long acc[20], tp; /* phase counters (profiling builds of the call only) */
     uint32_t dmax;      /* longest distance code + extra bits of the current block */
+    uint32_t mintok;    /* shortest literal/length code of the current block (every token is at least that long) */
     uint32_t maxtok;    /* longest token of the current block, bits (<= MAXTOK on the parallel path) */
 };
 
@@ -278,6 +279,7 @@ __device__ __forceinline__ uint32_t fast_token_entry(const ParShared &sh, uint32
 /* P1: exit function of the piece [s, s + SUBBITS) of the staged window.  Positions are handled
  * backwards in groups of 8: the 8 table lookups of a group are independent (their LDS latency
  * overlaps), only the 5-bit shift-register update is a dependent chain. */
+template <bool MIN4>
 __device__ __forceinline__ ExitFn piece_exit_fn(const ParShared &sh, uint32_t s)
 {
     unsigned long long lo = 0, hi = 0; /* entry d-1 = exit of position p+d */
@@ -303,22 +305,48 @@ __device__ __forceinline__ ExitFn piece_exit_fn(const ParShared &sh, uint32_t s)
             const uint32_t tj = token_bits(sh, b < 32u ? (w01 >> b) : (w12 >> (b - 32u)));
             T |= (unsigned long long)tj << (8u * j);
         }
+        if (MIN4) {
+            /* every token of this block is >= 4 bits: the four positions of a half group all land beyond it,
+             * so their four look-ups are independent and the shift register moves 4 entries (20 bits) at once */
 #pragma unroll
-        for (int j = 7; j >= 0; j--) {
-            const uint32_t k = 8u * (uint32_t)g + (uint32_t)j;
-            const uint32_t tt = (uint32_t)(T >> (8 * j)) & 255u;
-            unsigned long long ex;
-            if (tt >= X_ERR) ex = tt;
-            else if (k + tt >= (uint32_t)SUBBITS) ex = k + tt - (uint32_t)SUBBITS;
-            else {
-                const uint32_t e = tt - 1u;
-                const unsigned long long w = e < 12u ? lo : hi;
-                ex = (w >> (5u * (e < 12u ? e : e - 12u))) & 31ull;
+            for (int h = 1; h >= 0; h--) {
+                unsigned long long ins = 0;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int j = 4 * h + 3 - m;
+                    const uint32_t k = 8u * (uint32_t)g + (uint32_t)j;
+                    const uint32_t tt = (uint32_t)(T >> (8 * j)) & 255u;
+                    unsigned long long ex;
+                    if (tt >= X_ERR) ex = tt;
+                    else if (k + tt >= (uint32_t)SUBBITS) ex = k + tt - (uint32_t)SUBBITS;
+                    else {
+                        const uint32_t e = tt - (uint32_t)m - 1u; /* >= 0 because tt >= 4 > m */
+                        const unsigned long long w = e < 12u ? lo : hi;
+                        ex = (w >> (5u * (e < 12u ? e : e - 12u))) & 31ull;
+                    }
+                    ins |= ex << (5 * (3 - m)); /* position j0 + 3 - m -> entry 3 - m ... entry 0 = lowest position */
+                }
+                hi = (hi << 20) | ((lo >> 40) & 0xfffffull);
+                lo = (lo << 20) | ins;
             }
-            hi = ((hi << 5) | (lo >> 55)) & 0x0fffffffffffffffull;
-            lo = ((lo << 5) | ex) & 0x0fffffffffffffffull;
+        } else {
+    #pragma unroll
+            for (int j = 7; j >= 0; j--) {
+                const uint32_t k = 8u * (uint32_t)g + (uint32_t)j;
+                const uint32_t tt = (uint32_t)(T >> (8 * j)) & 255u;
+                unsigned long long ex;
+                if (tt >= X_ERR) ex = tt;
+                else if (k + tt >= (uint32_t)SUBBITS) ex = k + tt - (uint32_t)SUBBITS;
+                else {
+                    const uint32_t e = tt - 1u;
+                    const unsigned long long w = e < 12u ? lo : hi;
+                    ex = (w >> (5u * (e < 12u ? e : e - 12u))) & 31ull;
+                }
+                hi = ((hi << 5) | (lo >> 55)) & 0x0fffffffffffffffull;
+                lo = ((lo << 5) | ex) & 0x0fffffffffffffffull;
+            }
         }
-    }
+        }
     ExitFn f;
     f.lo = lo; f.hi = hi;
     return f;
@@ -650,6 +678,110 @@ __device__ __forceinline__ void hdr_lengths_wave0(ParShared &sh, int lane, uint3
 #undef HPH
 }
 
+/* The same resolution spread over the whole workgroup: 288 pieces of 16 bits (a code-length token is at
+ * most 14 bits), one per thread, so the per-block header costs a few thousand cycles instead of one
+ * wave's long dependent chain.  All PT threads call it (it contains barriers). */
+constexpr int HB2 = 16;   /* header bits per thread */
+constexpr int HNP = 288;  /* pieces: 4608 bits >= any dynamic header */
+
+__device__ __forceinline__ void hdr_lengths_block(ParShared &sh, int tid, uint32_t cur, uint32_t lead)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    const uint32_t hbase = sh.hpos + 3u * sh.ncode;
+    const uint32_t total = sh.nlen + sh.ndist;
+    const uint32_t ps = hbase + (uint32_t)(HB2 * tid);
+    const bool mine = tid < HNP;
+    unsigned long long chunk = 0;
+    if (mine) {
+        const uint32_t wi = ps >> 5, b0 = ps & 31u;
+        const unsigned long long w01 = (unsigned long long)sh.win[wi] | ((unsigned long long)sh.win[wi + 1] << 32);
+        chunk = w01 >> b0; /* >= 33 bits: 16 positions + 14 lookahead = 30 */
+    }
+    /* exit function: entry d-1 = exit of position p+d, 4 bits, 15 = invalid */
+    unsigned long long E = 0;
+    {
+        uint32_t tk[HB2];
+#pragma unroll
+        for (int j = 0; j < HB2; j++) tk[j] = mine ? hdr_token(sh, (uint32_t)(chunk >> j) & 0x3fffu) : 0u;
+#pragma unroll
+        for (int j = HB2 - 1; j >= 0; j--) {
+            const uint32_t t = tk[j] & 255u;
+            unsigned long long ex;
+            if (!tk[j]) ex = 15;
+            else if ((uint32_t)j + t >= (uint32_t)HB2) ex = (uint32_t)j + t - (uint32_t)HB2;
+            else ex = (E >> (4u * (t - 1u))) & 15ull;
+            E = (E << 4) | ex;
+        }
+    }
+    /* inclusive composition inside the wave, wave totals through LDS */
+    unsigned long long inc = E;
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const unsigned long long y = __shfl_up(inc, dd);
+        if (lane >= dd) {
+            unsigned long long r = 0;
+#pragma unroll
+            for (int e = 0; e < 14; e++) {
+                const uint32_t v = (uint32_t)(y >> (4 * e)) & 15u;
+                const unsigned long long o = v == 15u ? 15ull : ((inc >> (4u * v)) & 15ull);
+                r |= o << (4 * e);
+            }
+            inc = r;
+        }
+    }
+    if (lane == 63) sh.fnlo[wv] = inc;
+    const unsigned long long exc = __shfl_up(inc, 1);
+    __syncthreads();
+    uint32_t entry = 0;
+    for (int w2 = 0; w2 < wv && entry != 15u; w2++) entry = (uint32_t)(sh.fnlo[w2] >> (4u * entry)) & 15u;
+    if (lane != 0 && entry != 15u) entry = (uint32_t)(exc >> (4u * entry)) & 15u;
+    if (!mine) entry = 15u;
+    __syncthreads();
+    /* count walk (1..3 tokens) */
+    uint32_t cnt = 0, lastinfo = 0;
+    if (entry != 15u) {
+        uint32_t q = entry;
+        while (q < (uint32_t)HB2) {
+            const uint32_t tk = hdr_token(sh, (uint32_t)(chunk >> q) & 0x3fffu);
+            if (!tk) break;
+            q += tk & 255u;
+            cnt += (tk >> 8) & 255u;
+            const uint32_t kind = (tk >> 16) & 3u;
+            if (kind == 0u) lastinfo = 0x100u | (tk >> 24);
+            else if (kind == 2u) lastinfo = 0x100u;
+        }
+    }
+    uint32_t tot;
+    const uint32_t offs = block_excl_sum_pt(cnt, sh.scan_a, &tot);
+    const uint32_t prev = block_excl_last_pt(lastinfo, sh.scan_b);
+    if (tid == 0) sh.flag = 0;
+    __syncthreads();
+    /* write walk */
+    uint32_t endpos = 0xffffffffu, bad = 0;
+    if (entry != 15u && offs < total) {
+        uint32_t q = entry, idx = offs;
+        uint32_t pv = prev & 0xffu;
+        bool hp = (prev & 0x100u) != 0;
+        while (q < (uint32_t)HB2 && idx < total) {
+            const uint32_t tk = hdr_token(sh, (uint32_t)(chunk >> q) & 0x3fffu);
+            if (!tk) { bad = 1; break; }
+            q += tk & 255u;
+            const uint32_t n = (tk >> 8) & 255u, kind = (tk >> 16) & 3u;
+            uint32_t val;
+            if (kind == 0u) { val = tk >> 24; pv = val; hp = true; }
+            else if (kind == 1u) { if (!hp) { bad = 1; break; } val = pv; }
+            else { val = 0; pv = 0; hp = true; }
+            if (idx + n > total) { bad = 1; break; }
+            for (uint32_t k = 0; k < n; k++) sh.lens[idx + k] = (uint8_t)val;
+            idx += n;
+            if (idx == total) endpos = ps + q;
+        }
+    }
+    if (bad) atomicOr(&sh.flag, 1u);
+    if (endpos != 0xffffffffu) { sh.cur = cur + (endpos - lead); atomicOr(&sh.flag, 2u); }
+    __syncthreads();
+    if (tid == 0 && ((sh.flag & 1u) || !(sh.flag & 2u) || tot < total)) sh.status = 2; /* sequential decoder re-parses */
+}
+
 struct HdrCache {
     uint32_t valid, bfinal, nlen, ndist, cur_after, pad[3];
     uint8_t lens[320];
@@ -751,7 +883,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
             PHASE(12);
             huff_build(sh.dist, sh.bl, 19, tid, sh.bllut, 7);
             PHASE(13);
-            if (tid < 64) hdr_lengths_wave0(sh, tid, cur, lead, dbg != nullptr);
+            hdr_lengths_block(sh, tid, cur, lead);
             __syncthreads();
             if (sh.status != 0) return;
         }
@@ -790,7 +922,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
         sh.tn[i] = (uint16_t)nby;
     }
     /* longest token of this block: bounds the exit-function domain */
-    if (tid == 0) { sh.dmax = 0; sh.maxtok = 1; }
+    if (tid == 0) { sh.dmax = 0; sh.maxtok = 1; sh.mintok = 15; }
     __syncthreads();
     if ((uint32_t)tid < sh.ndist) {
         const uint32_t dl = sh.lens[sh.nlen + tid];
@@ -799,6 +931,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
     __syncthreads();
     if ((uint32_t)tid < sh.nlen) {
         const uint32_t ll = sh.lens[tid];
+        if (ll) atomicMin(&sh.mintok, ll);
         if (ll) atomicMax(&sh.maxtok, tid < 257 ? ll : ll + (uint32_t)len_extra_bits(tid - 257 < 29 ? tid - 257 : 0) + sh.dmax);
     }
     __syncthreads();
@@ -823,7 +956,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
             entry = ecache[(size_t)widx * PT + tid];
         } else {
             /* P1: exit function of my piece */
-            const ExitFn mine = piece_exit_fn(sh, pstart);
+            const ExitFn mine = sh.mintok >= 4u ? piece_exit_fn<true>(sh, pstart) : piece_exit_fn<false>(sh, pstart);
             PHASE(2);
             /* P2: inclusive Kogge-Stone scan of function composition across the wave */
             ExitFn inc = mine;
