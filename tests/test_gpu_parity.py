@@ -155,3 +155,42 @@ def test_one_gib_roundtrip_property(codec):
     # plane 0 is all zero after masking 8 bits: ~6 KiB per chunk; plane 1 is incompressible -> RAW
     assert rec.numel() < 0.6 * 4 * n
     big.close()
+
+
+def _container_from_python_zlib(words, strategy, level=6):
+    """A container in the reference's format whose plane streams were written by the system zlib with a
+    DIFFERENT strategy (general distances / fixed codes / Huffman only): exercises the decoder's
+    fallback paths (SURVEY 8(f)-4 decoder tolerance)."""
+    import zlib
+    n = len(words)
+    b = words.view(np.uint8).reshape(-1, 4)
+    out = bytearray(struct.pack("<QIb4b", 4 * n, util.CHUNK, 0, 0, 0, 0, 0))
+    for c0 in range(0, n, util.CHUNK):
+        c1 = min(n, c0 + util.CHUNK)
+        hdr, pay = bytearray(), bytearray()
+        for j in range(4):
+            plane = np.ascontiguousarray(b[c0:c1, j]).tobytes()
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+            z = co.compress(plane) + co.flush(zlib.Z_FULL_FLUSH)
+            if len(plane) > len(z) + 4:
+                hdr += struct.pack("<I", len(z))
+                pay += z
+            else:
+                hdr += struct.pack("<I", len(plane) | 0x80000000)
+                pay += plane
+        out += hdr + pay
+    return bytes(out)
+
+
+def test_foreign_streams_decode_through_fallbacks(codec):
+    import zlib
+    w = util.poisson_words(700000, seed=5)
+    w[300000:300400] = w[1000:1400]            # a long-distance repeat: distance != 1 under the default strategy
+    for strategy, expect_seq in ((zlib.Z_DEFAULT_STRATEGY, True), (zlib.Z_FIXED, False), (zlib.Z_HUFFMAN_ONLY, False), (zlib.Z_RLE, False)):
+        z = _container_from_python_zlib(w, strategy)
+        back = codec.unzip_bytes(z)
+        assert back == w.tobytes(), strategy
+        if expect_seq:
+            assert codec.last_fallbacks() > 0     # general distances went to the sequential decoder
+        if strategy == zlib.Z_RLE:
+            assert codec.last_fallbacks() == 0 and z == codec.zip_bytes(w.tobytes(), 0)
