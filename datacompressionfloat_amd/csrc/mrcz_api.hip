@@ -269,7 +269,7 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
                ctx->pairbits);
         LAUNCH("k_pair_offsets", k_pair_offsets, dim3(ns), dim3(64), ctx->sinfo, ctx->lay, ctx->tinfo, ctx->pairbits, ctx->pairoff);
         LAUNCH("k_container", k_container, dim3(1), dim3(256), ctx->sinfo, nb, out, ctx->result);
-        LAUNCH("k_emit", k_emit, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, ctx->tinfo, ctx->sinfo, ctx->lay, ctx->blkstart,
+        LAUNCH("k_emit", k_emit, dim3(SPS, nb, 4), dim3(64), bin, bfl, mask, fstart, ctx->tinfo, ctx->sinfo, ctx->lay, ctx->blkstart,
                ctx->blkcode, ctx->pairoff, out);
         LAUNCH("k_emit_headers", k_emit_headers, dim3(MAXBLK + 1, ns), dim3(64), ctx->sinfo, ctx->lay, ctx->meta, ctx->blkhdr,
                ctx->blkstart, out);

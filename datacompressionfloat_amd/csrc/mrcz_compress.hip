@@ -686,26 +686,25 @@ __device__ __forceinline__ void packer_finish(LanePacker &p)
     if (p.nacc > 0) atomicOr(&p.stage[p.word], (uint32_t)p.acc);
 }
 
-__global__ __launch_bounds__(256) void k_emit(const uint32_t *__restrict__ in, uint64_t nfloats, uint32_t mask,
+__global__ __launch_bounds__(64) void k_emit(const uint32_t *__restrict__ in, uint64_t nfloats, uint32_t mask,
                                               uint32_t first_chunk_is_file_start, const TileInfo *__restrict__ tinfo,
                                               const StreamInfo *__restrict__ sinfo, const BlkLay *__restrict__ lay,
                                               const uint32_t *__restrict__ blkstart, const uint32_t *__restrict__ blkcode,
                                               const uint32_t *__restrict__ pairoff, uint8_t *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PLANE_LDS];
-    __shared__ __attribute__((aligned(16))) uint32_t stage_all[4][STAGE_WORDS];
-    __shared__ uint32_t lut_all[4][HROW];
+    /* one wave = one (segment, plane): no workgroup barriers, light planes retire early */
+    __shared__ __attribute__((aligned(16))) uint8_t lds[PLANE_LDS];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[STAGE_WORDS];
+    __shared__ uint32_t lut[HROW];
     const uint32_t g = blockIdx.x, c = blockIdx.y;
     const uint64_t cbase = (uint64_t)c * CHK;
     const uint32_t n = (uint32_t)((nfloats - cbase) < CHK ? (nfloats - cbase) : CHK);
     if ((uint64_t)g * SEG >= n) return;
     const uint32_t *cin = in + cbase;
     const uint32_t unmasked = (c == 0 && first_chunk_is_file_start) ? 256u : 0u;
-    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int lane = lane_id(), w = (int)blockIdx.z;
     const uint32_t s = 4u * c + (uint32_t)w;
     const StreamInfo si = sinfo[s];
-    uint32_t *stage = stage_all[w];
-    uint32_t *lut = lut_all[w];
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
     const uint64_t paybit = si.payoff * 8ull;
     const uint32_t *bstart = blkstart + (size_t)s * (MAXBLK + 1);
@@ -721,9 +720,10 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t *__restrict__ in, u
         const uint32_t t0 = g * SEG + ti * TILE;
         if (t0 >= n) break;
         const int len = (int)((n - t0) < (uint32_t)TILE ? (n - t0) : (uint32_t)TILE);
-        stage_tile(cin, t0, (uint32_t)len, mask, unmasked, lds);
-        __syncthreads();
-        const uint8_t *plane = lds + w * PLANE_LDS;
+        __builtin_amdgcn_wave_barrier(); /* the previous tile's readers are done */
+        stage_tile_plane(cin, t0, (uint32_t)len, mask, unmasked, lds, w);
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t *plane = lds;
         const TileInfo tinf = tinfo[(size_t)s * TPS + (t0 / TILE)];
         uint32_t x[16];
         lane_row(plane, lane, x);
@@ -889,7 +889,6 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t *__restrict__ in, u
             }
             pos0 = pos1;
         }
-        __syncthreads();
     }
 }
 
