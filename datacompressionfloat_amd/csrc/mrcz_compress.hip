@@ -702,7 +702,9 @@ __global__ __launch_bounds__(64) void k_emit(const uint32_t *__restrict__ in, ui
     if ((uint64_t)g * SEG >= n) return;
     const uint32_t *cin = in + cbase;
     const uint32_t unmasked = (c == 0 && first_chunk_is_file_start) ? 256u : 0u;
-    const int lane = lane_id(), w = (int)blockIdx.z;
+    /* planes are dispatched heaviest first (mantissa-high and exponent bytes carry the coded symbols; the low
+     * bytes are mostly verbatim or masked to zero) so that the tail of the grid is made of short waves */
+    const int lane = lane_id(), w = (int)((0x0132u >> (4u * blockIdx.z)) & 3u);
     const uint32_t s = 4u * c + (uint32_t)w;
     const StreamInfo si = sinfo[s];
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);

@@ -53,7 +53,9 @@ using HuffDecD = HuffDecT<DBITS>;  /* distance code (also hosts the code-length 
 
 struct ParShared {
     uint32_t win[WIN_WORDS];
-    unsigned long long fnlo[PT / 64], fnhi[PT / 64]; /* exit function of each wave */
+    unsigned long long fnlo[PT / 64], fnhi[PT / 64]; /* exit function of each wave (header pieces) */
+    ulonglong2 pfn[PT];            /* exit function of every piece of the window (body pieces) */
+    uint8_t wtot[PT / 64][32];     /* exit function of each wave's 64 pieces, one byte per entry offset */
     uint32_t scan_a[PT / 64];
     uint32_t scan_b[PT / 64];
     HuffDec lit;
@@ -958,30 +960,47 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
             /* P1: exit function of my piece */
             const ExitFn mine = sh.mintok >= 4u ? piece_exit_fn<true>(sh, pstart) : piece_exit_fn<false>(sh, pstart);
             PHASE(2);
-            /* P2: inclusive Kogge-Stone scan of function composition across the wave */
-            ExitFn inc = mine;
+            /* P2: resolve every piece's entry offset.  Composing whole functions (24 look-ups each) in a scan
+             * is 24x redundant; instead the wave walks its 64 functions as a chain.  Pass 1: lane k < 24 of each
+             * 32-lane half follows entry offset k through the half's 32 pieces (the function of piece i is a
+             * broadcast LDS read), which yields the half's and then the wave's exit function.  After the waves'
+             * functions are chained (one barrier), pass 2 walks the same chain from the now known entry and
+             * lane i keeps the value in front of piece i. */
+            const int l = lane_id(), k = l & 31;
+            const ulonglong2 *hf = sh.pfn + ((tid & ~63) | (l & 32));
+            sh.pfn[tid] = make_ulonglong2(mine.lo, mine.hi);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t v = k < MAXTOK ? (uint32_t)k : (uint32_t)X_ERR;
+#pragma unroll 4
+            for (int i = 0; i < 32; i++) {
+                const ulonglong2 q = hf[i];
+                ExitFn f;
+                f.lo = q.x; f.hi = q.y;
+                if (v < (uint32_t)MAXTOK) v = fn_get(f, v);
+            }
             {
-                const int l = lane_id();
-                for (int dd = 1; dd < 64; dd <<= 1) {
-                    ExitFn y;
-                    y.lo = __shfl_up(inc.lo, dd);
-                    y.hi = __shfl_up(inc.hi, dd);
-                    if (l >= dd) inc = fn_compose(y, inc);
-                }
-                if (l == 63) { sh.fnlo[tid >> 6] = inc.lo; sh.fnhi[tid >> 6] = inc.hi; }
+                /* wave function = second half after first half */
+                const uint32_t second = (uint32_t)__shfl((int)v, 32 + (int)(v < (uint32_t)MAXTOK ? v : 0u));
+                const uint32_t tot = v < (uint32_t)MAXTOK ? second : v;
+                if (l < MAXTOK) sh.wtot[tid >> 6][l] = (uint8_t)tot;
             }
-            ExitFn exc; /* composition of the pieces before mine inside the wave */
-            exc.lo = __shfl_up(inc.lo, 1);
-            exc.hi = __shfl_up(inc.hi, 1);
             __syncthreads();
-            entry = 0; /* the window is staged so that its first piece starts on a token */
-            for (int ww = 0; ww < (tid >> 6) && entry < (uint32_t)MAXTOK; ww++) {
-                ExitFn t;
-                t.lo = sh.fnlo[ww]; t.hi = sh.fnhi[ww];
-                entry = fn_get(t, entry);
+            uint32_t e = 0; /* the window is staged so that its first piece starts on a token */
+            for (int ww = 0; ww < (tid >> 6) && e < (uint32_t)MAXTOK; ww++) e = sh.wtot[ww][e];
+            {
+                /* entry of the second half = first half's function at the wave entry */
+                const uint32_t h1 = (uint32_t)__shfl((int)v, (int)(e < (uint32_t)MAXTOK ? e : 0u));
+                if ((l & 32) && e < (uint32_t)MAXTOK) e = h1;
             }
-            if (lane_id() != 0 && entry < (uint32_t)MAXTOK) entry = fn_get(exc, entry);
-            __syncthreads();
+            entry = e;
+#pragma unroll 4
+            for (int i = 0; i < 32; i++) {
+                if (k == i) entry = e;
+                const ulonglong2 q = hf[i];
+                ExitFn f;
+                f.lo = q.x; f.hi = q.y;
+                if (e < (uint32_t)MAXTOK) e = fn_get(f, e);
+            }
             if (!WRITE && ecache != nullptr && widx < (uint32_t)ECACHE_WINDOWS) ecache[(size_t)widx * PT + tid] = (uint8_t)entry;
         }
         widx++;

@@ -43,6 +43,8 @@ enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDevice
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 r = {a, b, c, d}; return r; }
+struct alignas(16) ulonglong2 { unsigned long long x, y; };
+static inline ulonglong2 make_ulonglong2(unsigned long long a, unsigned long long b) { ulonglong2 r = {a, b}; return r; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r = {a, b}; return r; }
 
 /* ---- scheduler entry points (sim_runtime.cpp) ---- */
