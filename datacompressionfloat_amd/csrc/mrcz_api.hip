@@ -82,6 +82,9 @@ static int fail(mrcz_ctx *c, int code, const char *what, hipError_t e)
         if (e_ != hipSuccess) return fail(ctx, MRCZ_EHIP, what, e_); \
     } while (0)
 
+/* Occupancy of the decode kernels is set by LDS: three 512-thread workgroups per CU need 3 x this <= 160 KiB, and the
+ * hardware allocates LDS in 1280-byte granules (measured: at 54.4 KB only two workgroups were resident) */
+static_assert(((sizeof(ParShared) + 15u) & ~(size_t)15u) + 64u <= 42u * 1280u, "ParShared no longer fits three workgroups per CU");
 static size_t inflate_par_lds() { return ((sizeof(ParShared) + 15u) & ~(size_t)15u) + 64u; }
 
 template <typename T> static hipError_t dalloc(T **p, size_t count) { return hipMalloc((void **)p, count * sizeof(T)); }

@@ -37,32 +37,44 @@ constexpr int DBITS = 10;                     /* index bits of the distance fast
 constexpr uint32_t POS_INVALID = 0xffffffffu;
 enum { F_EOB = 1, F_ERR = 2, F_GENERAL = 4 };
 
-template <int TB>
-struct HuffDecT {
-    uint16_t lut[1 << TB]; /* sym | len << 9; 0 = code longer than the table's index bits (or unused) */
+/* canonical-code bookkeeping of one Huffman code (what the slow decode path needs) */
+template <int NSYM>
+struct HuffAuxT {
+    static constexpr int NW = (NSYM + 63) / 64;
     uint16_t limit[16];       /* left-justified (15-bit) upper bound of the codes of each length */
     uint16_t count[16];
     uint16_t first[16];
     uint16_t offs[16];
-    uint16_t sorted[320];
-    uint16_t wcnt[5][16];     /* per-wave (64 symbols) count of each code length */
+    uint16_t sorted[NSYM];
+    uint16_t wcnt[NW][16];    /* per-wave (64 symbols) count of each code length */
 };
-using HuffDec = HuffDecT<LBITS>;   /* literal/length code */
-using HuffDecD = HuffDecT<DBITS>;  /* distance code (also hosts the code-length code while a header is parsed) */
+using HuffAux = HuffAuxT<288>;  /* literal/length code: 286 symbols */
+/* distance code, 30 symbols (also hosts the 19-symbol code-length code while a header is parsed) */
+struct HuffDecD : HuffAuxT<32> {
+    uint16_t lut[1 << DBITS]; /* sym | len << 9; 0 = code longer than the table's index bits (or unused) */
+};
+/* The literal/length code has no table of its own: its fast entries share the dwords of ParShared::tok with the
+ * token tables, so that a walk step is ONE LDS read.  tok[idx], idx = next LBITS stream bits:
+ *   bits  0..7   total bits of the token when idx determines them (1..MAXTOK), X_EOB, X_ERR; 0 = general path
+ *   bits  8..16  plane bytes the token produces (1 literal, 3..258 match), TOK_NOTD1 = match with distance != 1
+ *   bits 17..25  literal/length symbol, bits 26..29 its code length (0 = code longer than LBITS) */
+constexpr uint32_t TOK_NOTD1 = 0x1ffu;
+constexpr int TOK_SYM_SHIFT = 17, TOK_LEN_SHIFT = 26;
 
 
 struct ParShared {
     uint32_t win[WIN_WORDS];
     unsigned long long fnlo[PT / 64], fnhi[PT / 64]; /* exit function of each wave (header pieces) */
-    ulonglong2 pfn[PT];            /* exit function of every piece of the window (body pieces) */
+    uint32_t ring[8][PT];          /* per-piece exit values: byte (k & 3) of ring[(k >> 2) & 7][piece] = exit of position k of that
+                                    * piece (k mod 32: a token is at most 24 bits); after P1 bytes 0..23 are the piece's exit function.
+                                    * A piece's dwords all sit in LDS bank (piece mod 32): its own gathers never conflict. */
     uint8_t wtot[PT / 64][32];     /* exit function of each wave's 64 pieces, one byte per entry offset */
     uint32_t scan_a[PT / 64];
     uint32_t scan_b[PT / 64];
-    HuffDec lit;
+    HuffAux lit;
+    uint32_t tok[1 << LBITS];
     HuffDecD dist;
     uint16_t bllut[128];      /* code-length code (<= 7 bits): sym | len << 9 */
-    uint8_t tb[1 << LBITS];   /* token bits when the 12 index bits determine them, 0 = take the general path */
-    uint16_t tn[1 << LBITS];  /* plane bytes that token produces (1 literal, 3..258 match); 0xffff = not distance 1 */
     uint8_t bl[32];           /* code-length code lengths */
     uint32_t ncode, hpos;
     uint8_t lens[320];
@@ -100,8 +112,8 @@ __device__ __forceinline__ uint32_t lb_get(LdsBits &b, int n)
 /* All PT threads (uniform control flow): canonical-code tables for `n` <= 320 code lengths.
  * Symbol t is owned by thread t; ranks among equal lengths come from wave ballots.  `lut` may be
  * h.lut (LBITS index bits) or a smaller table with `lutbits` index bits. */
-template <class H>
-__device__ __forceinline__ void huff_build(H &h, const uint8_t *lens, int n, int tid, uint16_t *lut, int lutbits)
+template <int SYMSHIFT, int LENSHIFT, class H, class LutT>
+__device__ __forceinline__ void huff_build(H &h, const uint8_t *lens, int n, int tid, LutT *lut, int lutbits)
 {
     const int w = tid >> 6, l = tid & 63;
     const int mylen = tid < n ? lens[tid] : 0;
@@ -109,12 +121,12 @@ __device__ __forceinline__ void huff_build(H &h, const uint8_t *lens, int n, int
     for (int len = 1; len <= 15; len++) {
         const unsigned long long m = __ballot(mylen == len);
         if (mylen == len) rank = __builtin_popcountll(m & ((1ull << l) - 1ull));
-        if (l == 0 && w < 5) h.wcnt[w][len] = (uint16_t)__builtin_popcountll(m);
+        if (l == 0 && w < H::NW) h.wcnt[w][len] = (uint16_t)__builtin_popcountll(m);
     }
     __syncthreads();
     if (tid < 16) {
         uint32_t c = 0;
-        if (tid >= 1) for (int ww = 0; ww < 5 && ww * 64 < n; ww++) c += h.wcnt[ww][tid];
+        if (tid >= 1) for (int ww = 0; ww < H::NW && ww * 64 < n; ww++) c += h.wcnt[ww][tid];
         h.count[tid] = (uint16_t)c;
     }
     __syncthreads();
@@ -149,9 +161,9 @@ __device__ __forceinline__ void huff_build(H &h, const uint8_t *lens, int n, int
         uint32_t e = 0;
         if (len) {
             const uint32_t d = (x >> (15 - len)) - h.first[len];
-            if (d < h.count[len]) e = (uint32_t)h.sorted[h.offs[len] + d] | ((uint32_t)len << 9);
+            if (d < h.count[len]) e = ((uint32_t)h.sorted[h.offs[len] + d] << SYMSHIFT) | ((uint32_t)len << LENSHIFT);
         }
-        lut[idx] = (uint16_t)e;
+        lut[idx] = (LutT)e;
     }
     __syncthreads();
 }
@@ -159,10 +171,8 @@ __device__ __forceinline__ void huff_build(H &h, const uint8_t *lens, int n, int
  * Codes longer than the table's index bits are resolved by comparing the left-justified 15-bit
  * prefix against the per-length limits (canonical codes are ordered by length), not by a bit loop. */
 template <int TBITS, class H>
-__device__ __forceinline__ uint32_t huff_decode_t(const H &h, uint32_t v)
+__device__ __forceinline__ uint32_t huff_decode_long(const H &h, uint32_t v)
 {
-    const uint32_t e = h.lut[v & ((1u << TBITS) - 1u)];
-    if (e) return (e & 511u) | ((e >> 9) << 16);
     const uint32_t x = __brev(v) >> 17; /* first 15 stream bits, MSB first */
     int l = TBITS + 1;
 #pragma unroll
@@ -172,8 +182,12 @@ __device__ __forceinline__ uint32_t huff_decode_t(const H &h, uint32_t v)
     if (d >= h.count[l]) return 0xffffffffu;
     return (uint32_t)h.sorted[h.offs[l] + d] | ((uint32_t)l << 16);
 }
-__device__ __forceinline__ uint32_t huff_decode(const HuffDec &h, uint32_t v) { return huff_decode_t<LBITS>(h, v); }
-__device__ __forceinline__ uint32_t huff_decode_dist(const HuffDecD &h, uint32_t v) { return huff_decode_t<DBITS>(h, v); }
+__device__ __forceinline__ uint32_t huff_decode_dist(const HuffDecD &h, uint32_t v)
+{
+    const uint32_t e = h.lut[v & ((1u << DBITS) - 1u)];
+    if (e) return (e & 511u) | ((e >> 9) << 16);
+    return huff_decode_long<DBITS>(h, v);
+}
 
 __device__ __forceinline__ uint32_t base_len_of(int lc) /* lc 0..28 -> match length base */
 {
@@ -230,11 +244,20 @@ __device__ __forceinline__ ExitFn fn_compose(const ExitFn &first, const ExitFn &
     return r;
 }
 
+__device__ __forceinline__ uint32_t huff_decode_lit(const ParShared &sh, uint32_t v)
+{
+    const uint32_t e = sh.tok[v & ((1u << LBITS) - 1u)];
+    if (e >> TOK_LEN_SHIFT) return ((e >> TOK_SYM_SHIFT) & 511u) | ((e >> TOK_LEN_SHIFT) << 16);
+    return huff_decode_long<LBITS>(sh.lit, v);
+}
+/* byte 0 of a tok entry (token bits) */
+__device__ __forceinline__ uint32_t tok_bits(const ParShared &sh, uint32_t idx) { return reinterpret_cast<const uint8_t *>(sh.tok)[4u * idx]; }
+
 /* total bits of the token that starts at the low bit of v (>= 33 valid bits): 1..MAXTOK, or
  * X_EOB (END_BLOCK) / X_ERR (invalid, or a token the parallel path does not resolve) */
 __device__ __forceinline__ uint32_t token_bits(const ParShared &sh, unsigned long long v)
 {
-    const uint32_t d = huff_decode(sh.lit, (uint32_t)v);
+    const uint32_t d = huff_decode_lit(sh, (uint32_t)v);
     if (d == 0xffffffffu) return X_ERR;
     const uint32_t l = d >> 16, sym = d & 0xffffu;
     if (sym < 256u) return l;
@@ -257,9 +280,9 @@ __device__ __forceinline__ uint32_t token_bits(const ParShared &sh, unsigned lon
 __device__ __forceinline__ uint32_t fast_token_entry(const ParShared &sh, uint32_t idx, uint32_t *nbytes)
 {
     *nbytes = 0;
-    const uint32_t e = sh.lit.lut[idx];
-    if (!e) return 0;
-    const uint32_t l = e >> 9, sym = e & 511u;
+    const uint32_t e = sh.tok[idx];
+    if (!(e >> TOK_LEN_SHIFT)) return 0;
+    const uint32_t l = e >> TOK_LEN_SHIFT, sym = (e >> TOK_SYM_SHIFT) & 511u;
     if (sym < 256u) { *nbytes = 1; return l; }
     if (sym == 256u) return X_EOB;
     const int lc = (int)sym - 257;
@@ -274,8 +297,57 @@ __device__ __forceinline__ uint32_t fast_token_entry(const ParShared &sh, uint32
     if (dc >= 30u) return X_ERR;
     const uint32_t dxb = dc < 4u ? 0u : (dc >> 1) - 1u;
     const uint32_t t = l + xb + dl + dxb;
-    *nbytes = dc == 0u ? base_len_of(lc) + ((idx >> l) & ((1u << xb) - 1u)) : 0xffffu;
+    *nbytes = dc == 0u ? base_len_of(lc) + ((idx >> l) & ((1u << xb) - 1u)) : TOK_NOTD1;
     return t > (uint32_t)MAXTOK ? X_ERR : t;
+}
+
+/* P1 for blocks whose tokens are all >= 4 bits (every literal-heavy block): exit values of the piece that starts
+ * at dword 8 * piece of the staged window, by a backward recurrence kept in LDS instead of registers:
+ *     exit[k] = k + t >= 256 ? k + t - 256 : exit[k + t]          (t = bits of the token that starts at position k)
+ * exit[] lives in the piece's column of ParShared::ring, indexed by k mod 32 (a token is at most 24 bits).  The
+ * dynamic index costs one LDS read instead of a dozen VALU bit-field operations on a register-held table, and
+ * this kernel is VALU-issue bound.  Four positions are handled together: with t >= 4 none of them can land on
+ * another one of the same group, so their 4 + 4 LDS reads are independent. */
+/* byte offset, inside ParShared::ring, of the exit value of position x (any x < 512) of piece 0 */
+__device__ __forceinline__ uint32_t ring_off(uint32_t x)
+{
+    /* x * 0x201 = x << 9 | x: bits 0..1 stay (byte in dword), bits 2..4 land on bits 11..13 (row * PT * 4) */
+    static_assert(PT * 4 == 2048, "ring_off assumes 2 KiB rows");
+    return (x * 0x201u) & 0x3803u;
+}
+template <bool TAIL>
+__device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int wq)
+{
+    const uint32_t wlo = sh.win[tid * (SUBBITS / 32) + (uint32_t)wq], whi = sh.win[tid * (SUBBITS / 32) + (uint32_t)wq + 1u];
+    const unsigned long long w01 = ((unsigned long long)whi << 32) | wlo;
+    const uint32_t kbase = 32u * (uint32_t)wq;
+    const uint8_t *col = reinterpret_cast<const uint8_t *>(&sh.ring[0][tid]);
+#pragma unroll
+    for (int q = 7; q >= 0; q--) {
+        uint32_t tt[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) tt[j] = tok_bits(sh, (uint32_t)(w01 >> (4 * q + j)) & ((1u << LBITS) - 1u));
+        if ((tt[0] == 0u) | (tt[1] == 0u) | (tt[2] == 0u) | (tt[3] == 0u)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (tt[j] == 0u) tt[j] = token_bits(sh, w01 >> (4 * q + j));
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = kbase + (uint32_t)(4 * q + j) + tt[j];
+            const uint32_t r = col[ring_off(x)];
+            uint32_t ex = tt[j] >= X_ERR ? tt[j] : r;
+            if (TAIL) ex = (tt[j] < X_ERR && x >= (uint32_t)SUBBITS) ? x - (uint32_t)SUBBITS : ex;
+            packed |= ex << (8 * j);
+        }
+        sh.ring[q][tid] = packed; /* positions kbase + 4q .. + 3 */
+    }
+}
+__device__ __forceinline__ void piece_exit_lds(ParShared &sh, uint32_t tid)
+{
+    piece_exit_word<true>(sh, tid, SUBBITS / 32 - 1);
+    for (int wq = SUBBITS / 32 - 2; wq >= 0; wq--) piece_exit_word<false>(sh, tid, wq);
 }
 
 /* P1: exit function of the piece [s, s + SUBBITS) of the staged window.  Positions are handled
@@ -296,7 +368,7 @@ __device__ __forceinline__ ExitFn piece_exit_fn(const ParShared &sh, uint32_t s)
         for (int j = 0; j < 8; j++) {
             const uint32_t b = b0 + (uint32_t)j;
             const unsigned long long v = b < 32u ? (w01 >> b) : (w12 >> (b - 32u));
-            const uint32_t tj = sh.tb[(uint32_t)v & ((1u << LBITS) - 1u)];
+            const uint32_t tj = tok_bits(sh, (uint32_t)v & ((1u << LBITS) - 1u));
             T |= (unsigned long long)tj << (8 * j);
             slow |= (tj == 0u ? 1u : 0u) << j;
         }
@@ -387,16 +459,16 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
     while (pos < limit) {
         if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
         const uint32_t idx = (uint32_t)buf & ((1u << LBITS) - 1u);
-        const uint32_t t = sh.tb[idx];
-        const uint32_t n = sh.tn[idx];
-        if (t - 1u < (uint32_t)MAXTOK && n != 0xffffu) { /* 1 <= t <= MAXTOK, distance 1 */
+        const uint32_t e = sh.tok[idx];
+        const uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
+        if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) { /* 1 <= t <= MAXTOK, distance 1 */
             buf >>= t; nb -= (int)t; pos += t;
             r.nout += n;
-            if (TRACK_LAST && n == 1u) r.lastlit = 0x100u | ((uint32_t)sh.lit.lut[idx] & 0xffu);
+            if (TRACK_LAST && n == 1u) r.lastlit = 0x100u | ((e >> TOK_SYM_SHIFT) & 0xffu);
             continue;
         }
         /* general path: long codes, END_BLOCK, other distances, errors */
-        const uint32_t d = huff_decode(sh.lit, (uint32_t)buf);
+        const uint32_t d = huff_decode_lit(sh, (uint32_t)buf);
         if (d == 0xffffffffu) { r.flags |= F_ERR; break; }
         const int l = (int)(d >> 16);
         const uint32_t sym = d & 0xffffu;
@@ -456,15 +528,15 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
     while (pos < limit) {
         if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
         const uint32_t idx = (uint32_t)buf & ((1u << LBITS) - 1u);
-        const uint32_t t = sh.tb[idx];
-        const uint32_t n = sh.tn[idx];
-        if (t - 1u < (uint32_t)MAXTOK && n != 0xffffu) {
-            if (n == 1u) { last = (uint32_t)sh.lit.lut[idx] & 0xffu; *out++ = (uint8_t)last; }
+        const uint32_t e = sh.tok[idx];
+        const uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
+        if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) {
+            if (n == 1u) { last = (e >> TOK_SYM_SHIFT) & 0xffu; *out++ = (uint8_t)last; }
             else { fill_global(out, last, n); out += n; }
             buf >>= t; nb -= (int)t; pos += t;
             continue;
         }
-        const uint32_t d = huff_decode(sh.lit, (uint32_t)buf);
+        const uint32_t d = huff_decode_lit(sh, (uint32_t)buf);
         if (d == 0xffffffffu) break;
         const int l = (int)(d >> 16);
         const uint32_t sym = d & 0xffffu;
@@ -548,6 +620,37 @@ __device__ __forceinline__ uint32_t stage_bits(uint32_t *dst, int nwords, const 
         dst[i] = v;
     }
     return (uint32_t)(gbit & 31u);
+}
+
+/* stage `nwords` dwords of payload bits so that bit 0 of dst[0] is payload bit `bit`: every piece of the window
+ * then starts on a dword and all bit offsets inside a piece are compile-time constants */
+__device__ __forceinline__ void stage_bits_aligned(uint32_t *dst, int nwords, const uint8_t *rec, uint64_t reclen,
+                                                   uint64_t paybit0, uint32_t bit)
+{
+    const uint64_t gbit = paybit0 + bit;
+    const uint64_t w0 = gbit >> 5;
+    const uint32_t lead = (uint32_t)(gbit & 31u);
+    const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
+    const uint64_t nrec32 = reclen >> 2; /* whole dwords available */
+    auto load = [&](uint64_t wi) -> uint32_t {
+        uint32_t x = 0;
+        if (wi < nrec32) x = rec32[wi];
+        else if (wi * 4 < reclen) { /* ragged tail of the records buffer */
+            for (uint64_t k = wi * 4; k < reclen; k++) x |= (uint32_t)rec[k] << (8 * (k - wi * 4));
+        }
+        return x;
+    };
+    const int rounds = (nwords + PT - 1) / PT;
+#pragma unroll 1
+    for (int rr = 0; rr < rounds; rr++) { /* uniform trip count: the shuffle below needs the whole wave */
+        const int i = rr * PT + (int)threadIdx.x;
+        uint32_t v[2];
+        v[0] = load(w0 + (uint64_t)i);
+        v[1] = (uint32_t)__shfl_down((int)v[0], 1);
+        if ((threadIdx.x & 63u) == 63u) v[1] = load(w0 + (uint64_t)i + 1u);
+        if (i < nwords)
+        dst[i] = (uint32_t)((((unsigned long long)v[1] << 32) | v[0]) >> lead);
+    }
 }
 
 /* The code lengths of a dynamic block (RFC 1951 3.2.7) are themselves a Huffman + run-length coded
@@ -883,7 +986,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
             }
             __syncthreads();
             PHASE(12);
-            huff_build(sh.dist, sh.bl, 19, tid, sh.bllut, 7);
+            huff_build<0, 9>(sh.dist, sh.bl, 19, tid, sh.bllut, 7);
             PHASE(13);
             hdr_lengths_block(sh, tid, cur, lead);
             __syncthreads();
@@ -914,14 +1017,14 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
         return;
     }
     PHASE(14);
-    huff_build(sh.lit, sh.lens, (int)sh.nlen, tid, sh.lit.lut, LBITS);
+    huff_build<TOK_SYM_SHIFT, TOK_LEN_SHIFT>(sh.lit, sh.lens, (int)sh.nlen, tid, sh.tok, LBITS);
     PHASE(15);
-    huff_build(sh.dist, sh.lens + sh.nlen, (int)sh.ndist, tid, sh.dist.lut, DBITS);
+    huff_build<0, 9>(sh.dist, sh.lens + sh.nlen, (int)sh.ndist, tid, sh.dist.lut, DBITS);
     PHASE(16);
     for (int i = tid; i < (1 << LBITS); i += PT) {
         uint32_t nby;
-        sh.tb[i] = (uint8_t)fast_token_entry(sh, (uint32_t)i, &nby);
-        sh.tn[i] = (uint16_t)nby;
+        const uint32_t t = fast_token_entry(sh, (uint32_t)i, &nby);
+        sh.tok[i] |= t | (nby << 8);
     }
     /* longest token of this block: bounds the exit-function domain */
     if (tid == 0) { sh.dmax = 0; sh.maxtok = 1; sh.mintok = 15; }
@@ -946,7 +1049,8 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
     for (;;) {
         if (dbg && tid == 0) sh.acc[11]++;
         const uint32_t wcur = sh.cur;
-        const uint32_t wlead = stage_bits(sh.win, WIN_WORDS, sv.rec, sv.reclen, sv.paybit0, wcur);
+        stage_bits_aligned(sh.win, WIN_WORDS, sv.rec, sv.reclen, sv.paybit0, wcur);
+        const uint32_t wlead = 0; /* the window starts on the first bit to decode */
         __syncthreads();
         PHASE(1);
         const uint32_t pstart = wlead + (uint32_t)tid * SUBBITS;
@@ -957,8 +1061,15 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
             /* the count pass already resolved this window: entry offset of every piece, one byte each */
             entry = ecache[(size_t)widx * PT + tid];
         } else {
-            /* P1: exit function of my piece */
-            const ExitFn mine = sh.mintok >= 4u ? piece_exit_fn<true>(sh, pstart) : piece_exit_fn<false>(sh, pstart);
+            /* P1: exit values of my piece -> my column of sh.ring (rows 0..23 = exit function) */
+            if (sh.mintok >= 4u) piece_exit_lds(sh, (uint32_t)tid);
+            else {
+                const ExitFn mine = piece_exit_fn<false>(sh, pstart);
+#pragma unroll
+                for (int r = 0; r < MAXTOK / 4; r++)
+                    sh.ring[r][tid] = fn_get(mine, 4u * r) | (fn_get(mine, 4u * r + 1u) << 8) | (fn_get(mine, 4u * r + 2u) << 16) |
+                                      (fn_get(mine, 4u * r + 3u) << 24);
+            }
             PHASE(2);
             /* P2: resolve every piece's entry offset.  Composing whole functions (24 look-ups each) in a scan
              * is 24x redundant; instead the wave walks its 64 functions as a chain.  Pass 1: lane k < 24 of each
@@ -967,17 +1078,12 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
              * functions are chained (one barrier), pass 2 walks the same chain from the now known entry and
              * lane i keeps the value in front of piece i. */
             const int l = lane_id(), k = l & 31;
-            const ulonglong2 *hf = sh.pfn + ((tid & ~63) | (l & 32));
-            sh.pfn[tid] = make_ulonglong2(mine.lo, mine.hi);
+            const uint8_t *hf = reinterpret_cast<const uint8_t *>(&sh.ring[0][(tid & ~63) | (l & 32)]); /* first piece of my half */
             __builtin_amdgcn_wave_barrier();
             uint32_t v = k < MAXTOK ? (uint32_t)k : (uint32_t)X_ERR;
 #pragma unroll 4
-            for (int i = 0; i < 32; i++) {
-                const ulonglong2 q = hf[i];
-                ExitFn f;
-                f.lo = q.x; f.hi = q.y;
-                if (v < (uint32_t)MAXTOK) v = fn_get(f, v);
-            }
+            for (int i = 0; i < 32; i++)
+                if (v < (uint32_t)MAXTOK) v = hf[ring_off(v) + 4u * (uint32_t)i];
             {
                 /* wave function = second half after first half */
                 const uint32_t second = (uint32_t)__shfl((int)v, 32 + (int)(v < (uint32_t)MAXTOK ? v : 0u));
@@ -996,10 +1102,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
 #pragma unroll 4
             for (int i = 0; i < 32; i++) {
                 if (k == i) entry = e;
-                const ulonglong2 q = hf[i];
-                ExitFn f;
-                f.lo = q.x; f.hi = q.y;
-                if (e < (uint32_t)MAXTOK) e = fn_get(f, e);
+                if (e < (uint32_t)MAXTOK) e = hf[ring_off(e) + 4u * (uint32_t)i];
             }
             if (!WRITE && ecache != nullptr && widx < (uint32_t)ECACHE_WINDOWS) ecache[(size_t)widx * PT + tid] = (uint8_t)entry;
         }
@@ -1268,7 +1371,7 @@ __global__ __launch_bounds__(256) void k_cand_index(const uint32_t *__restrict__
 
 /* D2: decode every candidate block without writing: where does it end, how many plane bytes does it
  * produce, what is its last byte */
-__global__ __launch_bounds__(PT) void k_blk_count(const uint8_t *__restrict__ rec, uint64_t reclen,
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_blk_count(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                   const DecStream *__restrict__ ds, uint32_t nstreams,
                                                   const uint32_t *__restrict__ candbase, Cand *__restrict__ cands,
                                                   uint8_t *__restrict__ planes, uint8_t *__restrict__ ecache, uint32_t ecache_rows,
@@ -1361,7 +1464,7 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
 }
 
 /* D4: decode the accepted blocks again, this time writing plane bytes at their final offsets */
-__global__ __launch_bounds__(PT) void k_blk_write(const uint8_t *__restrict__ rec, uint64_t reclen,
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_blk_write(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                   const DecStream *__restrict__ ds, const BlkJob *__restrict__ jobs,
                                                   const uint32_t *__restrict__ fallback, uint8_t *__restrict__ planes,
                                                   uint8_t *__restrict__ ecache, uint32_t ecache_rows, unsigned long long *__restrict__ dbg)
