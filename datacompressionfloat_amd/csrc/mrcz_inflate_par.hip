@@ -316,10 +316,13 @@ __device__ __forceinline__ uint32_t ring_off(uint32_t x)
     return (x * 0x201u) & 0x3803u;
 }
 template <bool TAIL>
-__device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int wq)
+__device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int wq, uint32_t lead)
 {
-    const uint32_t wlo = sh.win[tid * (SUBBITS / 32) + (uint32_t)wq], whi = sh.win[tid * (SUBBITS / 32) + (uint32_t)wq + 1u];
-    const unsigned long long w01 = ((unsigned long long)whi << 32) | wlo;
+    /* the window is staged dword-aligned, its first token starts `lead` (< 32) bits in: funnel the piece's dwords
+     * once per 32 positions so that every bit offset below is a compile-time constant */
+    const uint32_t *wp = sh.win + tid * (SUBBITS / 32) + (uint32_t)wq;
+    const unsigned long long a01 = ((unsigned long long)wp[1] << 32) | wp[0], a12 = ((unsigned long long)wp[2] << 32) | wp[1];
+    const unsigned long long w01 = ((a12 >> lead) << 32) | (uint32_t)(a01 >> lead);
     const uint32_t kbase = 32u * (uint32_t)wq;
     const uint8_t *col = reinterpret_cast<const uint8_t *>(&sh.ring[0][tid]);
 #pragma unroll
@@ -344,10 +347,10 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
         sh.ring[q][tid] = packed; /* positions kbase + 4q .. + 3 */
     }
 }
-__device__ __forceinline__ void piece_exit_lds(ParShared &sh, uint32_t tid)
+__device__ __forceinline__ void piece_exit_lds(ParShared &sh, uint32_t tid, uint32_t lead)
 {
-    piece_exit_word<true>(sh, tid, SUBBITS / 32 - 1);
-    for (int wq = SUBBITS / 32 - 2; wq >= 0; wq--) piece_exit_word<false>(sh, tid, wq);
+    piece_exit_word<true>(sh, tid, SUBBITS / 32 - 1, lead);
+    for (int wq = SUBBITS / 32 - 2; wq >= 0; wq--) piece_exit_word<false>(sh, tid, wq, lead);
 }
 
 /* P1: exit function of the piece [s, s + SUBBITS) of the staged window.  Positions are handled
@@ -620,37 +623,6 @@ __device__ __forceinline__ uint32_t stage_bits(uint32_t *dst, int nwords, const 
         dst[i] = v;
     }
     return (uint32_t)(gbit & 31u);
-}
-
-/* stage `nwords` dwords of payload bits so that bit 0 of dst[0] is payload bit `bit`: every piece of the window
- * then starts on a dword and all bit offsets inside a piece are compile-time constants */
-__device__ __forceinline__ void stage_bits_aligned(uint32_t *dst, int nwords, const uint8_t *rec, uint64_t reclen,
-                                                   uint64_t paybit0, uint32_t bit)
-{
-    const uint64_t gbit = paybit0 + bit;
-    const uint64_t w0 = gbit >> 5;
-    const uint32_t lead = (uint32_t)(gbit & 31u);
-    const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
-    const uint64_t nrec32 = reclen >> 2; /* whole dwords available */
-    auto load = [&](uint64_t wi) -> uint32_t {
-        uint32_t x = 0;
-        if (wi < nrec32) x = rec32[wi];
-        else if (wi * 4 < reclen) { /* ragged tail of the records buffer */
-            for (uint64_t k = wi * 4; k < reclen; k++) x |= (uint32_t)rec[k] << (8 * (k - wi * 4));
-        }
-        return x;
-    };
-    const int rounds = (nwords + PT - 1) / PT;
-#pragma unroll 1
-    for (int rr = 0; rr < rounds; rr++) { /* uniform trip count: the shuffle below needs the whole wave */
-        const int i = rr * PT + (int)threadIdx.x;
-        uint32_t v[2];
-        v[0] = load(w0 + (uint64_t)i);
-        v[1] = (uint32_t)__shfl_down((int)v[0], 1);
-        if ((threadIdx.x & 63u) == 63u) v[1] = load(w0 + (uint64_t)i + 1u);
-        if (i < nwords)
-        dst[i] = (uint32_t)((((unsigned long long)v[1] << 32) | v[0]) >> lead);
-    }
 }
 
 /* The code lengths of a dynamic block (RFC 1951 3.2.7) are themselves a Huffman + run-length coded
@@ -1049,8 +1021,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
     for (;;) {
         if (dbg && tid == 0) sh.acc[11]++;
         const uint32_t wcur = sh.cur;
-        stage_bits_aligned(sh.win, WIN_WORDS, sv.rec, sv.reclen, sv.paybit0, wcur);
-        const uint32_t wlead = 0; /* the window starts on the first bit to decode */
+        const uint32_t wlead = stage_bits(sh.win, WIN_WORDS, sv.rec, sv.reclen, sv.paybit0, wcur);
         __syncthreads();
         PHASE(1);
         const uint32_t pstart = wlead + (uint32_t)tid * SUBBITS;
@@ -1062,7 +1033,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
             entry = ecache[(size_t)widx * PT + tid];
         } else {
             /* P1: exit values of my piece -> my column of sh.ring (rows 0..23 = exit function) */
-            if (sh.mintok >= 4u) piece_exit_lds(sh, (uint32_t)tid);
+            if (sh.mintok >= 4u) piece_exit_lds(sh, (uint32_t)tid, wlead);
             else {
                 const ExitFn mine = piece_exit_fn<false>(sh, pstart);
 #pragma unroll
