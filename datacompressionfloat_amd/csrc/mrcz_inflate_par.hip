@@ -504,20 +504,66 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
     return r;
 }
 
-/* `n` copies of byte b at p (a distance-1 match): short runs byte by byte, long runs with 16-byte
- * aligned stores */
-__device__ __forceinline__ void fill_global(uint8_t *p, uint32_t b, uint32_t n)
+/* Per-lane output packer of the write walk.  A lane's plane bytes are contiguous in HBM but start at any byte
+ * address and come one token at a time; storing them byte by byte costs one scattered store instruction per
+ * byte.  The packer collects them in a 64-bit register and stores aligned dwords; only the bytes of the lane's
+ * first and last (partial) dword go out as byte stores, because those dwords are shared with the neighbouring
+ * lanes' ranges. */
+struct OutPacker {
+    uint8_t *p;              /* dword-aligned address the low bytes of acc belong to */
+    unsigned long long acc;  /* pending bytes, byte j belongs at p[j] */
+    uint32_t fill;           /* bytes held in acc (the `head` dummy bytes included) */
+    uint32_t head;           /* bytes of the first dword that lie before the lane's range */
+};
+__device__ __forceinline__ void pk_init(OutPacker &k, uint8_t *out)
 {
-    if (n < 32u) {
-        for (uint32_t k = 0; k < n; k++) p[k] = (uint8_t)b;
-        return;
+    const uint32_t mis = (uint32_t)((uintptr_t)out & 3u);
+    k.p = out - mis;
+    k.acc = 0;
+    k.fill = mis;
+    k.head = mis;
+}
+__device__ __forceinline__ void pk_flush_word(OutPacker &k)
+{
+    const uint32_t w = (uint32_t)k.acc;
+    if (k.head) {
+        for (uint32_t j = k.head; j < 4u; j++) k.p[j] = (uint8_t)(w >> (8u * j));
+        k.head = 0;
+    } else *reinterpret_cast<uint32_t *>(k.p) = w;
+    k.p += 4;
+    k.acc >>= 32;
+    k.fill -= 4u;
+}
+__device__ __forceinline__ void pk_put(OutPacker &k, uint32_t b)
+{
+    k.acc |= (unsigned long long)b << (8u * k.fill);
+    k.fill++;
+    if (k.fill >= 4u) pk_flush_word(k);
+}
+/* `n` copies of byte b (a distance-1 match) */
+__device__ __forceinline__ void pk_run(OutPacker &k, uint32_t b, uint32_t n)
+{
+    const unsigned long long pat = 0x0101010101010101ull * (unsigned long long)b;
+    if (n >= 48u) {
+        /* long run: byte-feed up to a 16-byte boundary, then whole 16-byte stores */
+        while ((((uintptr_t)k.p + k.fill) & 15u) != 0u) { pk_put(k, b); n--; }
+        const uint32_t w = (uint32_t)pat;
+        const uint4 v = make_uint4(w, w, w, w);
+        for (; n >= 16u; n -= 16u) { *reinterpret_cast<uint4 *>(k.p) = v; k.p += 16; }
     }
-    uint32_t k = 0;
-    while ((uintptr_t)(p + k) & 15u) p[k++] = (uint8_t)b;
-    const uint32_t w = 0x01010101u * b;
-    const uint4 v = make_uint4(w, w, w, w);
-    for (; k + 16u <= n; k += 16u) *reinterpret_cast<uint4 *>(p + k) = v;
-    for (; k < n; k++) p[k] = (uint8_t)b;
+    while (n) {
+        const uint32_t room = 8u - k.fill; /* fill < 4 here, so room >= 5 */
+        const uint32_t take = n < room ? n : room;
+        const unsigned long long m = take >= 8u ? ~0ull : ((1ull << (8u * take)) - 1ull);
+        k.acc |= (pat & m) << (8u * k.fill);
+        k.fill += take;
+        n -= take;
+        while (k.fill >= 4u) pk_flush_word(k);
+    }
+}
+__device__ __forceinline__ void pk_finish(OutPacker &k)
+{
+    for (uint32_t j = k.head; j < k.fill; j++) k.p[j] = (uint8_t)(k.acc >> (8u * j));
 }
 
 /* P4 walk of one lane: decode its piece from `start` and write the plane bytes at `out` */
@@ -528,14 +574,16 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
     uint64_t buf = ((uint64_t)sh.win[wi] | ((uint64_t)sh.win[wi + 1] << 32)) >> (pos & 31u);
     int nb = 64 - (int)(pos & 31u);
     wi += 2;
+    OutPacker pk;
+    pk_init(pk, out);
     while (pos < limit) {
         if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
         const uint32_t idx = (uint32_t)buf & ((1u << LBITS) - 1u);
         const uint32_t e = sh.tok[idx];
         const uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
         if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) {
-            if (n == 1u) { last = (e >> TOK_SYM_SHIFT) & 0xffu; *out++ = (uint8_t)last; }
-            else { fill_global(out, last, n); out += n; }
+            if (n == 1u) { last = (e >> TOK_SYM_SHIFT) & 0xffu; pk_put(pk, last); }
+            else pk_run(pk, last, n);
             buf >>= t; nb -= (int)t; pos += t;
             continue;
         }
@@ -544,7 +592,7 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
         const int l = (int)(d >> 16);
         const uint32_t sym = d & 0xffffu;
         buf >>= l; nb -= l; pos += (uint32_t)l;
-        if (sym < 256u) { last = sym; *out++ = (uint8_t)sym; }
+        if (sym < 256u) { last = sym; pk_put(pk, sym); }
         else if (sym == 256u) break;
         else {
             const int lc = (int)sym - 257;
@@ -556,10 +604,10 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
             const int dl = (int)(dd >> 16), dc = (int)(dd & 0xffffu);
             const int dxb = dc < 4 ? 0 : (dc >> 1) - 1;
             buf >>= (dl + dxb); nb -= dl + dxb; pos += (uint32_t)(dl + dxb);
-            fill_global(out, last, ml);
-            out += ml;
+            pk_run(pk, last, ml);
         }
     }
+    pk_finish(pk);
 }
 
 
