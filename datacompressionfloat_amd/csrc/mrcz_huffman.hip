@@ -7,7 +7,8 @@
  * order and tie rules, repair over-long codes, assign canonical codes, and pre-pack the dynamic
  * block header.  SURVEY.md Appendix B.3 is the specification.  One GPU thread owns one block; all
  * per-tree arrays live in LDS, interleaved across the workgroup's threads so that equal indices of
- * different trees fall into different banks.
+ * different trees fall into different banks.  Frequencies are only ever read with wide loads whose
+ * addresses do not depend on the tree (a dependent global load per leaf costs more than the heap).
  *
  * Heap entries are packed keys  freq << 16 | depth << 10 | node  so that zlib's
  *   smaller(n, m) = freq[n] < freq[m] || (freq[n] == freq[m] && depth[n] <= depth[m])
@@ -17,44 +18,43 @@
 
 namespace mrcz {
 
-constexpr int HT = 24;        /* trees (threads) per workgroup; 24 x ~2.6 KB = 62 KB of LDS */
+constexpr int HT = 48;        /* trees (threads) per workgroup: 48 x 1.5 KB = 72 KB of LDS, two workgroups per CU */
 constexpr int LELEMS = 286;
 constexpr int BLELEMS = 19;
+constexpr int HSLOTS = 288;
 
+/* Per-tree LDS is what bounds this kernel (one thread per tree, every step a dependent LDS access, so the only
+ * way to go faster is more trees in flight per CU).  Hence:
+ *  - the merge records (zlib keeps the removed nodes at the top of its heap array) go into the slot the shrinking
+ *    heap frees at that very merge: record i = n_i | m_i << 10 lives in slot n0 - i, and later also carries the
+ *    code length of internal node i in bits 20..24;
+ *  - the bit-length tree's arrays reuse the heap region once the literal/length tree is finished. */
 struct TreeMem {
-    uint32_t heap[288 * HT];        /* heap keys; afterwards reused as u8 code-length arrays */
-    uint16_t ord[576 * HT];         /* extraction order: ord[2i] = n_i, ord[2i+1] = m_i */
+    uint32_t heap[HSLOTS * HT];
+    uint8_t leaflen[HSLOTS * HT];   /* literal/length code lengths */
     uint16_t blcount[16 * HT];
     uint16_t nextcode[16 * HT];
-    uint16_t blfreq[BLELEMS * HT];
-    uint32_t blheap[20 * HT];
-    uint16_t blord[40 * HT];
-    uint8_t bllen[40 * HT];         /* [0,19): leaf lengths, [19,38): internal node lengths */
-    uint16_t blcode[BLELEMS * HT];
 };
 
 #define HEAP(i) tm.heap[(i) * HT + tid]
-#define ORD(i) tm.ord[(i) * HT + tid]
+#define LEAFLEN(i) tm.leaflen[(i) * HT + tid]
 #define BLCOUNT(i) tm.blcount[(i) * HT + tid]
 #define NEXTCODE(i) tm.nextcode[(i) * HT + tid]
-#define BLFREQ(i) tm.blfreq[(i) * HT + tid]
-#define BLHEAP(i) tm.blheap[(i) * HT + tid]
-#define BLORD(i) tm.blord[(i) * HT + tid]
-#define BLLEN(i) tm.bllen[(i) * HT + tid]
-#define BLCODE(i) tm.blcode[(i) * HT + tid]
-#define LENLEAF(i) lenb[(i) * HT + tid]
-#define LENINT(i) lenb[(LELEMS + (i)) * HT + tid]
+/* bit-length tree, inside the heap region: heap + merge records in slots 1..19 */
+#define BLFREQ(i) HEAP(32 + (i))
+#define BLLEN(i) HEAP(64 + (i))
+#define BLCODE(i) HEAP(96 + (i))
 
-__device__ __forceinline__ void sift_down(uint32_t *heap, int tid, int heap_len, int k)
+/* zlib's pqdownheap with the value to place passed in a register.  Both children are always read (the index of a
+ * missing right child is clamped), so the two LDS reads of a level are independent. */
+__device__ __forceinline__ void sift_down(uint32_t *heap, int tid, int heap_len, int k, uint32_t v)
 {
-    const uint32_t v = heap[k * HT + tid];
     int j = k << 1;
     while (j <= heap_len) {
+        const int j1 = j < heap_len ? j + 1 : j;
         uint32_t cj = heap[j * HT + tid];
-        if (j < heap_len) {
-            const uint32_t cj1 = heap[(j + 1) * HT + tid];
-            if ((cj1 >> 10) <= (cj >> 10)) { j++; cj = cj1; }
-        }
+        const uint32_t cj1 = heap[j1 * HT + tid];
+        if (j1 != j && (cj1 >> 10) <= (cj >> 10)) { j = j1; cj = cj1; }
         if ((v >> 10) <= (cj >> 10)) break;
         heap[k * HT + tid] = cj;
         k = j;
@@ -63,28 +63,32 @@ __device__ __forceinline__ void sift_down(uint32_t *heap, int tid, int heap_len,
     heap[k * HT + tid] = v;
 }
 
-/* heap holds heap_len leaf keys (1-based).  Runs zlib's merge loop; returns the number of merges.
- * ord[2i], ord[2i+1] receive the two nodes removed in merge i; internal node ids are elems + i. */
-__device__ __forceinline__ int merge_loop(uint32_t *heap, uint16_t *ord, int tid, int heap_len, int elems)
+/* heap holds n0 leaf keys (1-based).  Runs zlib's merge loop; returns the number of merges.  Merge i removes
+ * n_i then m_i and creates internal node elems + i; its record lands in slot n0 - i. */
+__device__ __forceinline__ int merge_loop(uint32_t *heap, int tid, int n0, int elems)
 {
-    for (int k = heap_len / 2; k >= 1; k--) sift_down(heap, tid, heap_len, k);
-    int it = 0;
+    for (int k = n0 / 2; k >= 1; k--) sift_down(heap, tid, n0, k, heap[k * HT + tid]);
+    int heap_len = n0, it = 0;
     do {
         const uint32_t nkey = heap[1 * HT + tid];
-        heap[1 * HT + tid] = heap[heap_len * HT + tid];
+        const uint32_t lastv = heap[heap_len * HT + tid];
         heap_len--;
-        sift_down(heap, tid, heap_len, 1);
+        sift_down(heap, tid, heap_len, 1, lastv);
         const uint32_t mkey = heap[1 * HT + tid];
-        ord[(2 * it) * HT + tid] = (uint16_t)(nkey & 0x3ffu);
-        ord[(2 * it + 1) * HT + tid] = (uint16_t)(mkey & 0x3ffu);
+        heap[(heap_len + 1) * HT + tid] = (nkey & 0x3ffu) | ((mkey & 0x3ffu) << 10);
         const uint32_t f = (nkey >> 16) + (mkey >> 16);
         const uint32_t dn = (nkey >> 10) & 63u, dm = (mkey >> 10) & 63u;
         const uint32_t d = (dn >= dm ? dn : dm) + 1u;
-        heap[1 * HT + tid] = (f << 16) | (d << 10) | (uint32_t)(elems + it);
+        sift_down(heap, tid, heap_len, 1, (f << 16) | (d << 10) | (uint32_t)(elems + it));
         it++;
-        sift_down(heap, tid, heap_len, 1);
     } while (heap_len >= 2);
     return it;
+}
+/* h-th node in zlib's removal order (n_0, m_0, n_1, m_1, ...) */
+__device__ __forceinline__ int removed_node(const uint32_t *heap, int tid, int n0, int h)
+{
+    const uint32_t w = heap[(n0 - (h >> 1)) * HT + tid];
+    return (int)((h & 1) ? (w >> 10) & 0x3ffu : w & 0x3ffu);
 }
 
 struct HdrWriter {
@@ -148,6 +152,9 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
 {
     __shared__ TreeMem tm;
     const int tid = threadIdx.x;
+    /* all-zero code lengths for every tree of the workgroup (one wave: cooperative, before anyone leaves) */
+    for (int w = tid; w < HSLOTS * HT / 4; w += HT) reinterpret_cast<uint32_t *>(tm.leaflen)[w] = 0;
+    __builtin_amdgcn_wave_barrier();
     const uint32_t job = blockIdx.x * HT + tid;
     const uint32_t total = blkbase[nstreams];
     if (job >= total) return;
@@ -159,36 +166,37 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
     }
     const uint32_t s = lo, b = job - blkbase[lo];
     const uint16_t *fq = blkfreq + ((size_t)s * MAXBLK + b) * HROW;
+    const uint4 *fq8 = reinterpret_cast<const uint4 *>(fq); /* 8 frequencies per load */
     uint32_t *code_out = blkcode + ((size_t)s * MAXBLK + b) * HROW;
-    uint8_t *lenb = reinterpret_cast<uint8_t *>(tm.heap);
 
     /* ---------------- literal/length tree ---------------- */
     int n = 0, max_lcode = -1;
-    for (int sym = 0; sym < LELEMS; sym++) {
-        const uint32_t f = (sym == 256) ? 1u : (uint32_t)fq[sym];
-        if (f) { n++; HEAP(n) = (f << 16) | (uint32_t)sym; max_lcode = sym; }
+    for (int g = 0; g < HROW / 8; g++) {
+        const uint4 fv = fq8[g];
+        const uint32_t fw[4] = {fv.x, fv.y, fv.z, fv.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int sym = 8 * g + j;
+            if (sym >= LELEMS) continue;
+            const uint32_t f = (sym == 256) ? 1u : ((fw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+            if (f) { n++; HEAP(n) = (f << 16) | (uint32_t)sym; max_lcode = sym; }
+        }
     }
     /* a block always holds >= 1 symbol besides END_BLOCK, so n >= 2 (zlib's "force 2 codes" rule never fires) */
-    const int niter = merge_loop(tm.heap, tm.ord, tid, n, LELEMS);
+    const int niter = merge_loop(tm.heap, tid, n, LELEMS);
 
-    long opt_len = 0, static_len = 0;
     int overflow = 0;
     for (int i = 0; i < 16; i++) BLCOUNT(i) = 0;
-    for (int i = 0; i < LELEMS; i++) LENLEAF(i) = 0; /* heap keys are dead now */
-    LENINT(niter - 1) = 0; /* root */
     for (int it = niter - 1; it >= 0; it--) {
-        const int L = LENINT(it);
+        const uint32_t w = HEAP(n - it);
+        const int L = (int)(w >> 20); /* the root's record still has 0 there */
         for (int side = 1; side >= 0; side--) { /* zlib walks m_i then n_i */
-            const int child = ORD(2 * it + side);
+            const int child = (int)(side ? (w >> 10) & 0x3ffu : w & 0x3ffu);
             int bits = L + 1;
             if (bits > 15) { bits = 15; overflow++; }
-            if (child >= LELEMS) { LENINT(child - LELEMS) = (uint8_t)bits; continue; }
-            LENLEAF(child) = (uint8_t)bits;
+            if (child >= LELEMS) { HEAP(n - (child - LELEMS)) |= (uint32_t)bits << 20; continue; }
+            LEAFLEN(child) = (uint8_t)bits;
             BLCOUNT(bits) = (uint16_t)(BLCOUNT(bits) + 1);
-            const uint32_t f = (child == 256) ? 1u : (uint32_t)fq[child];
-            const int xb = child >= 257 ? len_extra_bits(child - 257) : 0;
-            opt_len += (long)f * (bits + xb);
-            static_len += (long)f * (static_llen(child) + xb);
         }
     }
     if (overflow > 0) {
@@ -204,38 +212,49 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
         for (int bits = 15; bits != 0; bits--) {
             int cnt = BLCOUNT(bits);
             while (cnt != 0) {
-                const int m = ORD(h);
+                const int m = removed_node(tm.heap, tid, n, h);
                 h++;
                 if (m >= LELEMS) continue;
-                const int old = LENLEAF(m);
-                if (old != bits) {
-                    const uint32_t f = (m == 256) ? 1u : (uint32_t)fq[m];
-                    opt_len += ((long)bits - (long)old) * (long)f;
-                    LENLEAF(m) = (uint8_t)bits;
-                }
+                if (LEAFLEN(m) != bits) LEAFLEN(m) = (uint8_t)bits;
                 cnt--;
             }
         }
     }
-    /* canonical codes */
+    /* canonical codes, and the block's cost under the dynamic and the static code (zlib keeps both sums up to
+     * date while it assigns and repairs lengths; they only depend on the final lengths) */
+    long opt_len = 0, static_len = 0;
+    uint32_t eob = 0;
     {
         uint32_t c = 0;
         for (int bits = 1; bits <= 15; bits++) {
             c = (c + BLCOUNT(bits - 1)) << 1;
             NEXTCODE(bits) = (uint16_t)c;
         }
-        for (int sym = 0; sym < LELEMS; sym++) {
-            const int l = sym <= max_lcode ? LENLEAF(sym) : 0;
-            uint32_t e = 0;
-            if (l) {
-                const uint32_t cd = NEXTCODE(l);
-                NEXTCODE(l) = (uint16_t)(cd + 1);
-                e = bit_reverse(cd, l) | ((uint32_t)l << 16);
+        for (int g = 0; g < HROW / 8; g++) {
+            const uint4 fv = fq8[g];
+            const uint32_t fw[4] = {fv.x, fv.y, fv.z, fv.w};
+            uint32_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int sym = 8 * g + j;
+                e[j] = 0;
+                if (sym >= LELEMS) continue;
+                const int l = LEAFLEN(sym);
+                if (l) {
+                    const uint32_t f = (sym == 256) ? 1u : ((fw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                    const uint32_t cd = NEXTCODE(l);
+                    NEXTCODE(l) = (uint16_t)(cd + 1);
+                    e[j] = bit_reverse(cd, l) | ((uint32_t)l << 16);
+                    const int xb = sym >= 257 ? len_extra_bits(sym - 257) : 0;
+                    opt_len += (long)f * (l + xb);
+                    static_len += (long)f * (static_llen(sym) + xb);
+                    if (sym == 256) eob = e[j];
+                }
             }
-            code_out[sym] = e;
+            reinterpret_cast<uint4 *>(code_out)[2 * g] = make_uint4(e[0], e[1], e[2], e[3]);
+            reinterpret_cast<uint4 *>(code_out)[2 * g + 1] = make_uint4(e[4], e[5], e[6], e[7]);
         }
     }
-    const uint32_t eob = code_out[256];
 
     /* ---------------- distance tree (only code 0 can occur: distance 1) ----------------
      * nmatch > 0: freq[0] = nmatch, node 1 forced with freq 1 -> both length 1, opt += nmatch,
@@ -244,23 +263,23 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
     opt_len += (long)nmatch;
     static_len += 5L * (long)nmatch;
 
-    /* ---------------- bit-length tree ---------------- */
-    for (int i = 0; i < BLELEMS; i++) BLFREQ(i) = 0;
+    /* ---------------- bit-length tree (its arrays live in the heap region from here on) ---------------- */
+    for (int i = 0; i < BLELEMS; i++) { BLFREQ(i) = 0; BLLEN(i) = 0; }
     /* scan_tree over literal/length lengths [0, max_lcode], then over the distance lengths {1, 1} */
     for (int pass = 0; pass < 2; pass++) {
         const int maxc = pass == 0 ? max_lcode : 1;
-        int prevlen = -1, nextlen = pass == 0 ? LENLEAF(0) : 1, count = 0, max_count = 7, min_count = 4;
+        int prevlen = -1, nextlen = pass == 0 ? LEAFLEN(0) : 1, count = 0, max_count = 7, min_count = 4;
         if (nextlen == 0) { max_count = 138; min_count = 3; }
         for (int i = 0; i <= maxc; i++) {
             const int curlen = nextlen;
-            nextlen = (i + 1 <= maxc) ? (pass == 0 ? LENLEAF(i + 1) : 1) : 0xffff;
+            nextlen = (i + 1 <= maxc) ? (pass == 0 ? LEAFLEN(i + 1) : 1) : 0xffff;
             if (++count < max_count && curlen == nextlen) continue;
-            else if (count < min_count) BLFREQ(curlen) = (uint16_t)(BLFREQ(curlen) + count);
+            else if (count < min_count) BLFREQ(curlen) += (uint32_t)count;
             else if (curlen != 0) {
-                if (curlen != prevlen) BLFREQ(curlen) = (uint16_t)(BLFREQ(curlen) + 1);
-                BLFREQ(16) = (uint16_t)(BLFREQ(16) + 1);
-            } else if (count <= 10) BLFREQ(17) = (uint16_t)(BLFREQ(17) + 1);
-            else BLFREQ(18) = (uint16_t)(BLFREQ(18) + 1);
+                if (curlen != prevlen) BLFREQ(curlen) += 1u;
+                BLFREQ(16) += 1u;
+            } else if (count <= 10) BLFREQ(17) += 1u;
+            else BLFREQ(18) += 1u;
             count = 0;
             prevlen = curlen;
             if (nextlen == 0) { max_count = 138; min_count = 3; }
@@ -271,31 +290,28 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
     int bn = 0, bl_max = -1;
     for (int i = 0; i < BLELEMS; i++) {
         const uint32_t f = BLFREQ(i);
-        if (f) { bn++; BLHEAP(bn) = (f << 16) | (uint32_t)i; bl_max = i; }
+        if (f) { bn++; HEAP(bn) = (f << 16) | (uint32_t)i; bl_max = i; }
     }
     while (bn < 2) { /* zlib: force at least two codes of non zero frequency */
         const int node = bl_max < 2 ? ++bl_max : 0;
         BLFREQ(node) = 1;
         bn++;
-        BLHEAP(bn) = (1u << 16) | (uint32_t)node;
+        HEAP(bn) = (1u << 16) | (uint32_t)node;
         opt_len--;
     }
-    const int bniter = merge_loop(tm.blheap, tm.blord, tid, bn, BLELEMS);
+    const int bniter = merge_loop(tm.heap, tid, bn, BLELEMS);
     for (int i = 0; i < 16; i++) BLCOUNT(i) = 0;
-    for (int i = 0; i < 38; i++) BLLEN(i) = 0;
     overflow = 0;
-    BLLEN(19 + bniter - 1) = 0;
     for (int it = bniter - 1; it >= 0; it--) {
-        const int L = BLLEN(19 + it);
+        const uint32_t w = HEAP(bn - it);
+        const int L = (int)(w >> 20);
         for (int side = 1; side >= 0; side--) {
-            const int child = BLORD(2 * it + side);
+            const int child = (int)(side ? (w >> 10) & 0x3ffu : w & 0x3ffu);
             int bits = L + 1;
             if (bits > 7) { bits = 7; overflow++; }
-            if (child >= BLELEMS) { BLLEN(19 + child - BLELEMS) = (uint8_t)bits; continue; }
-            BLLEN(child) = (uint8_t)bits;
+            if (child >= BLELEMS) { HEAP(bn - (child - BLELEMS)) |= (uint32_t)bits << 20; continue; }
+            BLLEN(child) = (uint32_t)bits;
             BLCOUNT(bits) = (uint16_t)(BLCOUNT(bits) + 1);
-            const int xb = child == 16 ? 2 : child == 17 ? 3 : child == 18 ? 7 : 0;
-            opt_len += (long)BLFREQ(child) * (bits + xb);
         }
     }
     if (overflow > 0) {
@@ -311,14 +327,10 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
         for (int bits = 7; bits != 0; bits--) {
             int cnt = BLCOUNT(bits);
             while (cnt != 0) {
-                const int m = BLORD(h);
+                const int m = removed_node(tm.heap, tid, bn, h);
                 h++;
                 if (m >= BLELEMS) continue;
-                const int old = BLLEN(m);
-                if (old != bits) {
-                    opt_len += ((long)bits - (long)old) * (long)BLFREQ(m);
-                    BLLEN(m) = (uint8_t)bits;
-                }
+                if ((int)BLLEN(m) != bits) BLLEN(m) = (uint32_t)bits;
                 cnt--;
             }
         }
@@ -330,11 +342,13 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
             NEXTCODE(bits) = (uint16_t)c;
         }
         for (int sym = 0; sym <= bl_max; sym++) {
-            const int l = BLLEN(sym);
+            const int l = (int)BLLEN(sym);
             if (!l) continue;
             const uint32_t cd = NEXTCODE(l);
             NEXTCODE(l) = (uint16_t)(cd + 1);
-            BLCODE(sym) = (uint16_t)bit_reverse(cd, l);
+            BLCODE(sym) = bit_reverse(cd, l);
+            const int xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+            opt_len += (long)BLFREQ(sym) * (l + xb);
         }
     }
     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -358,11 +372,11 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
     }
     for (int pass = 0; pass < 2; pass++) {
         const int maxc = pass == 0 ? max_lcode : 1;
-        int prevlen = -1, nextlen = pass == 0 ? LENLEAF(0) : 1, count = 0, max_count = 7, min_count = 4;
+        int prevlen = -1, nextlen = pass == 0 ? LEAFLEN(0) : 1, count = 0, max_count = 7, min_count = 4;
         if (nextlen == 0) { max_count = 138; min_count = 3; }
         for (int i = 0; i <= maxc; i++) {
             const int curlen = nextlen;
-            nextlen = (i + 1 <= maxc) ? (pass == 0 ? LENLEAF(i + 1) : 1) : 0xffff;
+            nextlen = (i + 1 <= maxc) ? (pass == 0 ? LEAFLEN(i + 1) : 1) : 0xffff;
             if (++count < max_count && curlen == nextlen) continue;
             else if (count < min_count) {
                 do { hw_put(hw, BLCODE(curlen), BLLEN(curlen)); } while (--count != 0);
