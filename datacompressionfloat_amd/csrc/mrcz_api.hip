@@ -58,7 +58,7 @@ struct mrcz_ctx {
     uint32_t *h_counts;    /* pinned: totals read back between the decode stages */
     unsigned long long *dbgphase; /* 8 counters per stream when phase profiling is on */
     int phase_profile;
-    uint8_t *planes;       /* decode only, allocated lazily */
+    uint8_t *planes;       /* byte planes of one batch (stream s at s * CHK), both directions; allocated on first use */
     /* timing */
     int timing;
     int ntimers;
@@ -233,6 +233,15 @@ extern "C" int mrcz_last_timings(const mrcz_ctx_t *ctx, const char **names, floa
 
 static uint32_t mask_of(int bits) { return bits >= 32 ? 0u : (0xFFFFFFFFu << bits); } /* workers.c:29-37 */
 
+/* byte-plane workspace of one batch: 4 planes x max_chunks x CHK bytes (as large as the batch's floats) */
+static int ensure_planes(mrcz_ctx *ctx)
+{
+    if (ctx->planes) return MRCZ_OK;
+    hipError_t e = hipMalloc((void **)&ctx->planes, (size_t)4 * ctx->max_chunks * CHK);
+    if (e != hipSuccess) { ctx->planes = NULL; return fail(ctx, MRCZ_ENOMEM, "plane workspace", e); }
+    return MRCZ_OK;
+}
+
 extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk, int bits,
                                     void *d_out, uint64_t out_cap, uint64_t *out_len, uint64_t plane_bytes[4])
 {
@@ -249,6 +258,7 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
     const uint64_t nchunks = (nfloats + CHK - 1) / CHK;
     const uint32_t *in = (const uint32_t *)d_in;
     uint8_t *out = (uint8_t *)d_out;
+    if (int rc = ensure_planes(ctx)) return rc;
     HIPCHK(hipMemsetAsync(ctx->result, 0, 8 * sizeof(uint64_t), ctx->stream), "memset result");
     HIPCHK(hipMemsetAsync(out, 0, (size_t)((bound + 3u) & ~3ull), ctx->stream), "memset output");
 
@@ -259,10 +269,10 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
         const uint64_t bfl = (nfloats - c0 * CHK) < (uint64_t)nb * CHK ? (nfloats - c0 * CHK) : (uint64_t)nb * CHK;
         const uint32_t fstart = (first_chunk + c0 == 0) ? 1u : 0u;
         ctx->last_streams = ns;
-        LAUNCH("k_tile_summary", k_tile_summary, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, ctx->tsum);
+        LAUNCH("k_tile_summary", k_tile_summary, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, ctx->tsum, ctx->planes);
         LAUNCH("k_stream_scan", k_stream_scan, dim3(ns), dim3(256), ctx->tsum, bfl, ctx->tinfo, ctx->sinfo, ctx->blkstart);
-        LAUNCH("k_histogram", k_histogram, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, ctx->tinfo, ctx->pairhist,
-               ctx->blkstart, ctx->slideq);
+        LAUNCH("k_histogram", k_histogram, dim3(SPS, nb, 4), dim3(64), ctx->planes, bfl, ctx->tinfo, ctx->pairhist, ctx->blkstart,
+               ctx->slideq);
         LAUNCH("k_block_reduce", k_block_reduce, dim3(MAXBLK, ns), dim3(64), ctx->tinfo, ctx->sinfo, ctx->pairhist, ctx->blkfreq);
         LAUNCH("k_block_index", k_block_index, dim3(1), dim3(256), ctx->sinfo, ns, ctx->blkbase);
         LAUNCH("k_huffman", k_huffman, dim3((ns * MAXBLK + HT - 1) / HT), dim3(HT), ctx->sinfo, ns, ctx->blkbase, ctx->blkfreq,
@@ -272,7 +282,7 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
                ctx->pairbits);
         LAUNCH("k_pair_offsets", k_pair_offsets, dim3(ns), dim3(64), ctx->sinfo, ctx->lay, ctx->tinfo, ctx->pairbits, ctx->pairoff);
         LAUNCH("k_container", k_container, dim3(1), dim3(256), ctx->sinfo, nb, out, ctx->result);
-        LAUNCH("k_emit", k_emit, dim3(SPS, nb, 4), dim3(64), bin, bfl, mask, fstart, ctx->tinfo, ctx->sinfo, ctx->lay, ctx->blkstart,
+        LAUNCH("k_emit", k_emit, dim3(SPS, nb, 4), dim3(64), ctx->planes, bfl, ctx->tinfo, ctx->sinfo, ctx->lay, ctx->blkstart,
                ctx->blkcode, ctx->pairoff, out);
         LAUNCH("k_emit_headers", k_emit_headers, dim3(MAXBLK + 1, ns), dim3(64), ctx->sinfo, ctx->lay, ctx->meta, ctx->blkhdr,
                ctx->blkstart, out);
@@ -296,10 +306,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
     if (chk == 0 || chk > CHK) return fail(ctx, MRCZ_EFORMAT, "chunk size in header exceeds CHUNK_SIZE (constant.h:25)", hipSuccess);
     if (((uintptr_t)d_out & 15u) || ((uintptr_t)d_records & 3u)) return fail(ctx, MRCZ_EINVAL, "d_out must be 16-byte and d_records 4-byte aligned", hipSuccess);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    if (!ctx->planes) {
-        hipError_t e = hipMalloc((void **)&ctx->planes, (size_t)4 * ctx->max_chunks * CHK);
-        if (e != hipSuccess) return fail(ctx, MRCZ_ENOMEM, "plane workspace", e);
-    }
+    if (int rc = ensure_planes(ctx)) return rc;
     const uint8_t *rec = (const uint8_t *)d_records;
     uint32_t *out = (uint32_t *)d_out;
     const uint64_t nchunks = (nfloats + chk - 1) / chk;

@@ -6,17 +6,19 @@
  * (workers.c:82-101,180-203) and 4 x mzlib_def (zip.c:164-196), i.e. zlib 1.2.8
  * deflate(level 6, raw, memLevel 9, Z_RLE, Z_FULL_FLUSH) -- emitted bit-exactly.
  *
- * Pass structure (all passes read the float input directly; planes are never materialised in HBM):
- *   k_tile_summary   4N B read : per (stream, tile) run summary + interior symbol count
+ * Pass structure.  The first pass reads the floats once and leaves the four masked byte planes in HBM (N bytes
+ * each); the two later streaming passes read a plane per wave, so the heavy planes (coded symbols) and the light
+ * ones (all-zero, verbatim) are balanced by the hardware scheduler instead of idling side by side in a workgroup.
+ *   k_tile_summary   4N B read, N B x 4 written : masked byte planes, per (stream, tile) run summary + interior symbol count
  *   k_stream_scan    small     : run extensions across tiles, symbol prefix, block count
- *   k_histogram      4N B read : per (segment, block) "pair" histograms, block start positions,
+ *   k_histogram      N B x 4 read : per (segment, block) "pair" histograms, block start positions,
  *                                window-slide positions (App. B.4)
  *   k_block_reduce   small     : block histograms
  *   k_huffman        small     : zlib-exact Huffman construction, dynamic headers      (mrcz_huffman.hip)
  *   k_stream_layout  small     : stored/static/dynamic choice, block bit offsets, RAW test
  *   k_pair_bits/_off small     : bit offset of every pair
  *   k_container      small     : payload offsets + 16-byte chunk headers
- *   k_emit           4N B read, Z B written : Huffman/stored/raw bit packing
+ *   k_emit           N B x 4 read, Z B written : Huffman/stored/raw bit packing
  *   k_emit_headers   small     : block headers, END_BLOCK codes, sync markers
  * No MFMA anywhere: the path is byte/bit manipulation bound by HBM and LDS.
  */
@@ -29,7 +31,7 @@ namespace mrcz {
  * ==================================================================================== */
 __global__ __launch_bounds__(256) void k_tile_summary(const uint32_t *__restrict__ in, uint64_t nfloats,
                                                       uint32_t mask, uint32_t first_chunk_is_file_start,
-                                                      TileSum *__restrict__ tsum)
+                                                      TileSum *__restrict__ tsum, uint8_t *__restrict__ planes)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PLANE_LDS];
     const uint32_t g = blockIdx.x, c = blockIdx.y;
@@ -50,6 +52,11 @@ __global__ __launch_bounds__(256) void k_tile_summary(const uint32_t *__restrict
         const uint8_t *plane = lds + w * PLANE_LDS;
         uint32_t x[16];
         lane_row(plane, lane, x);
+        if (64 * lane < len) { /* the masked plane, for the later passes: stream s at planes + s * CHK, 64 B per lane */
+            uint4 *dst = reinterpret_cast<uint4 *>(planes + (size_t)s * CHK + t0 + 64u * (uint32_t)lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++) dst[k] = make_uint4(x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]);
+        }
         const LaneTile lt = analyse_lane(x, lane, len, 0u, 0u);
         /* head: first run start at tile position >= 1 */
         const uint64_t Eh = (lane == 0) ? (lt.E & ~1ull) : lt.E;
@@ -291,23 +298,41 @@ __device__ __forceinline__ int token_boundary_at(const LaneTile &lt, const LaneC
     return p - m + l;
 }
 
-__global__ __launch_bounds__(256) void k_histogram(const uint32_t *__restrict__ in, uint64_t nfloats, uint32_t mask,
-                                                   uint32_t first_chunk_is_file_start,
-                                                   const TileInfo *__restrict__ tinfo, uint16_t *__restrict__ pairhist,
-                                                   uint32_t *__restrict__ blkstart, uint32_t *__restrict__ slideq)
+/* the lane's 64 consecutive plane bytes of tile t0 (zeros past the end of the chunk), straight from the plane in HBM */
+__device__ __forceinline__ void load_plane_row(const uint8_t *__restrict__ pl, uint32_t t0, int len, int lane, uint32_t x[16])
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PLANE_LDS];
-    __shared__ uint32_t rows[4][2][HROW];
+    if (64 * lane < len) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(pl + t0 + 64u * (uint32_t)lane);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 v = src[k];
+            x[4 * k + 0] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = 0;
+    }
+}
+/* planes are dispatched heaviest first (mantissa-high and exponent bytes carry the coded symbols; the low bytes are
+ * mostly verbatim or masked to zero) so that the tail of a (segment, chunk, plane) grid is made of short waves */
+__device__ __forceinline__ int plane_of_slot(uint32_t z) { return (int)((0x0132u >> (4u * z)) & 3u); }
+
+__global__ __launch_bounds__(64) void k_histogram(const uint8_t *__restrict__ planes, uint64_t nfloats,
+                                                  const TileInfo *__restrict__ tinfo, uint16_t *__restrict__ pairhist,
+                                                  uint32_t *__restrict__ blkstart, uint32_t *__restrict__ slideq)
+{
+    /* one wave = one (segment, plane) */
+    __shared__ uint32_t rows[2][HROW];
     const uint32_t g = blockIdx.x, c = blockIdx.y;
     const uint64_t cbase = (uint64_t)c * CHK;
     const uint32_t n = (uint32_t)((nfloats - cbase) < CHK ? (nfloats - cbase) : CHK);
     if ((uint64_t)g * SEG >= n) return;
-    const uint32_t *cin = in + cbase;
-    const uint32_t unmasked = (c == 0 && first_chunk_is_file_start) ? 256u : 0u;
-    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const int lane = lane_id(), w = plane_of_slot(blockIdx.z);
     const uint32_t s = 4u * c + (uint32_t)w;
-    uint32_t *rowA = rows[w][0], *rowB = rows[w][1];
+    const uint8_t *pl = planes + (size_t)s * CHK;
+    uint32_t *rowA = rows[0], *rowB = rows[1];
     for (int i = lane; i < HROW; i += 64) { rowA[i] = 0; rowB[i] = 0; }
+    __builtin_amdgcn_wave_barrier();
     const uint32_t nslide = slide_count(n);
     uint32_t curBlk = 0xffffffffu;
 
@@ -315,13 +340,10 @@ __global__ __launch_bounds__(256) void k_histogram(const uint32_t *__restrict__ 
         const uint32_t t0 = g * SEG + ti * TILE;
         if (t0 >= n) break;
         const int len = (int)((n - t0) < (uint32_t)TILE ? (n - t0) : (uint32_t)TILE);
-        stage_tile(cin, t0, (uint32_t)len, mask, unmasked, lds);
-        __syncthreads();
-        const uint8_t *plane = lds + w * PLANE_LDS;
         const TileInfo tinf = tinfo[(size_t)s * TPS + (t0 / TILE)];
         if (curBlk == 0xffffffffu) curBlk = tinf.P / BLK_SYMS;
         uint32_t x[16];
-        lane_row(plane, lane, x);
+        load_plane_row(pl, t0, len, lane, x);
         const LaneTile lt = analyse_lane(x, lane, len, tinf.B, tinf.F);
         const LaneCls cls = classify_lane(lt.E, lt.a, lt.prevS, lt.nextS);
         const uint64_t S = cls.S & lt.V, M = cls.M & lt.V;
@@ -391,7 +413,7 @@ __global__ __launch_bounds__(256) void k_histogram(const uint32_t *__restrict__ 
                 atomicAdd(&r[286], 1u);
             }
         }
-        __syncthreads(); /* all waves done with lds (and this wave's row updates are complete) */
+        __builtin_amdgcn_wave_barrier(); /* this wave's row updates are complete */
         /* crossed (or exactly reached) the block boundary: retire row A */
         if (tinf.P + tot >= nextBnd) {
             uint16_t *dst = pairhist + ((size_t)s * MAXPAIR + (g + curBlk)) * HROW;
@@ -401,11 +423,13 @@ __global__ __launch_bounds__(256) void k_histogram(const uint32_t *__restrict__ 
                 rowB[i] = 0;
             }
             curBlk++;
+            __builtin_amdgcn_wave_barrier();
         }
     }
     /* segment end: always retire the open row (possibly empty) so every pair (g, b) with
      * b in [blk(P_g), blk(P_{g+1})] exists */
     {
+        __builtin_amdgcn_wave_barrier();
         uint16_t *dst = pairhist + ((size_t)s * MAXPAIR + (g + curBlk)) * HROW;
         for (int i = lane; i < HROW; i += 64) dst[i] = (uint16_t)rowA[i];
     }
@@ -686,8 +710,7 @@ __device__ __forceinline__ void packer_finish(LanePacker &p)
     if (p.nacc > 0) atomicOr(&p.stage[p.word], (uint32_t)p.acc);
 }
 
-__global__ __launch_bounds__(64) void k_emit(const uint32_t *__restrict__ in, uint64_t nfloats, uint32_t mask,
-                                              uint32_t first_chunk_is_file_start, const TileInfo *__restrict__ tinfo,
+__global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes, uint64_t nfloats, const TileInfo *__restrict__ tinfo,
                                               const StreamInfo *__restrict__ sinfo, const BlkLay *__restrict__ lay,
                                               const uint32_t *__restrict__ blkstart, const uint32_t *__restrict__ blkcode,
                                               const uint32_t *__restrict__ pairoff, uint8_t *__restrict__ out)
@@ -700,12 +723,9 @@ __global__ __launch_bounds__(64) void k_emit(const uint32_t *__restrict__ in, ui
     const uint64_t cbase = (uint64_t)c * CHK;
     const uint32_t n = (uint32_t)((nfloats - cbase) < CHK ? (nfloats - cbase) : CHK);
     if ((uint64_t)g * SEG >= n) return;
-    const uint32_t *cin = in + cbase;
-    const uint32_t unmasked = (c == 0 && first_chunk_is_file_start) ? 256u : 0u;
-    /* planes are dispatched heaviest first (mantissa-high and exponent bytes carry the coded symbols; the low
-     * bytes are mostly verbatim or masked to zero) so that the tail of the grid is made of short waves */
-    const int lane = lane_id(), w = (int)((0x0132u >> (4u * blockIdx.z)) & 3u);
+    const int lane = lane_id(), w = plane_of_slot(blockIdx.z);
     const uint32_t s = 4u * c + (uint32_t)w;
+    const uint8_t *pl = planes + (size_t)s * CHK;
     const StreamInfo si = sinfo[s];
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
     const uint64_t paybit = si.payoff * 8ull;
@@ -723,12 +743,18 @@ __global__ __launch_bounds__(64) void k_emit(const uint32_t *__restrict__ in, ui
         if (t0 >= n) break;
         const int len = (int)((n - t0) < (uint32_t)TILE ? (n - t0) : (uint32_t)TILE);
         __builtin_amdgcn_wave_barrier(); /* the previous tile's readers are done */
-        stage_tile_plane(cin, t0, (uint32_t)len, mask, unmasked, lds, w);
+        uint32_t x[16];
+        load_plane_row(pl, t0, len, lane, x);
+        {
+            /* the tile also goes to LDS: the verbatim path reads it byte-wise across lanes, the coded path re-reads
+             * its own row in quarters to keep the packer's register footprint small */
+            uint4 *row = reinterpret_cast<uint4 *>(lds + lane * ROWPAD);
+#pragma unroll
+            for (int k = 0; k < 4; k++) row[k] = make_uint4(x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]);
+        }
         __builtin_amdgcn_wave_barrier();
         const uint8_t *plane = lds;
         const TileInfo tinf = tinfo[(size_t)s * TPS + (t0 / TILE)];
-        uint32_t x[16];
-        lane_row(plane, lane, x);
         const LaneTile lt = analyse_lane(x, lane, len, tinf.B, tinf.F);
         const LaneCls cls = classify_lane(lt.E, lt.a, lt.prevS, lt.nextS);
 

@@ -53,40 +53,6 @@ __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ cin, uin
     }
 }
 
-/* One wave: stage only plane `w` of tile [t0, t0+len) into its own LDS tile (PLANE_LDS bytes).  Used by
- * kernels that give every (segment, plane) its own single-wave workgroup so that light planes (all-zero,
- * RAW) retire early instead of idling next to the heavy ones; the float tile is then read by four waves
- * (from L2) instead of one. */
-__device__ __forceinline__ void stage_tile_plane(const uint32_t *__restrict__ cin, uint32_t t0, uint32_t len, uint32_t mask,
-                                                 uint32_t unmasked_below, uint8_t *plane_lds, int w)
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll 4
-    for (int k = 0; k < 16; k++) {
-        const uint32_t p = 4u * ((uint32_t)lane + 64u * (uint32_t)k);
-        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-        if (p + 4u <= len) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(cin + t0 + p);
-            w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
-        } else if (p < len) {
-            w0 = cin[t0 + p];
-            if (p + 1u < len) w1 = cin[t0 + p + 1u];
-            if (p + 2u < len) w2 = cin[t0 + p + 2u];
-        }
-        const uint32_t gp = t0 + p;
-        if (gp >= unmasked_below) {
-            w0 &= mask; w1 &= mask; w2 &= mask; w3 &= mask;
-        } else {
-            if (gp + 1u >= unmasked_below) w1 &= mask;
-            if (gp + 2u >= unmasked_below) w2 &= mask;
-            if (gp + 3u >= unmasked_below) w3 &= mask;
-        }
-        const uint32_t sh = 8u * (uint32_t)w;
-        const uint32_t pw = ((w0 >> sh) & 0xffu) | (((w1 >> sh) & 0xffu) << 8) | (((w2 >> sh) & 0xffu) << 16) | (((w3 >> sh) & 0xffu) << 24);
-        *reinterpret_cast<uint32_t *>(plane_lds + (p >> 6) * ROWPAD + (p & 63u)) = pw;
-    }
-}
-
 /* the lane's 64 consecutive plane bytes as 16 words */
 __device__ __forceinline__ void lane_row(const uint8_t *plane, int lane, uint32_t x[16])
 {
