@@ -326,7 +326,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
             /* block-parallel path: find block starts, size every candidate block, close the chains, write */
             LAUNCH("k_scan_candidates", k_scan_candidates, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(256), rec, len,
                    ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 1, ctx->rawcap);
-            LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(256), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 1,
+            LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 1,
                    ctx->rawcap, ctx->cands, ctx->ncand);
             LAUNCH("k_cand_index", k_cand_index, dim3(1), dim3(256), ctx->ncand, ns, ctx->candbase);
             HIPCHK(hipMemcpyAsync(ctx->h_counts, ctx->candbase + ns, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy ncand");

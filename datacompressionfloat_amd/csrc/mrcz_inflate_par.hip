@@ -1190,6 +1190,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
  * kernels
  * ==================================================================================== */
 constexpr int MAXCAND = 1024; /* block-start candidates kept per stream */
+constexpr int SCAN_QCAP = 256 + 7 * 256; /* k_scan_candidates: positions waiting for the second test (drained at 256; <= 7 per dword and step) */
 struct Cand {
     uint32_t bit;    /* payload bit where a block (seems to) start */
     uint32_t end;    /* first bit after its END_BLOCK */
@@ -1252,23 +1253,50 @@ __global__ __launch_bounds__(256) void k_scan_candidates(const uint8_t *__restri
     const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
     const uint64_t nrec32 = reclen >> 2;
     const uint64_t gbit0 = gbyte0 * 8ull;
-    /* coalesced: in step k the 256 threads test the 32 positions starting in 256 consecutive dwords */
+    /* Pass 1 (all lanes busy): in step k the 256 threads test, bit-parallel, the 32 positions that start in 256
+     * consecutive dwords, and only QUEUE the ~1/273 positions whose fixed header fields fit.  Pass 2 (drain, once
+     * 256 positions wait or the slab ends): one queued position per lane gets the code-length-code test, which
+     * costs three more dependent loads.  Testing hits in place would make every wave pay that latency for the one
+     * or two lanes that have a hit. */
+    __shared__ uint32_t queue[SCAN_QCAP];
+    __shared__ uint32_t qn;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
     const uint64_t w_first = gbit0 >> 5;           /* gbyte0 may be unaligned: positions are global bits */
     const uint64_t bit_lo = gbit0, bit_hi = gbit0 + 8ull * SLAB_BYTES;
-    for (int k = 0; k < SLAB_BYTES / 4 / 256 + 1; k++) {
-        const uint64_t wi = w_first + (uint64_t)k * 256u + threadIdx.x;
-        const uint32_t w0 = wi < nrec32 ? rec32[wi] : 0u, w1 = wi + 1 < nrec32 ? rec32[wi + 1] : 0u;
+    constexpr int NSTEP = SLAB_BYTES / 4 / 256 + 1;
+    uint32_t w0, w1;
+    {
+        const uint64_t wi = w_first + threadIdx.x;
+        w0 = wi < nrec32 ? rec32[wi] : 0u;
+        w1 = wi + 1 < nrec32 ? rec32[wi + 1] : 0u;
+    }
+    for (int k = 0; k < NSTEP; k++) {
         const unsigned long long win = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
-        /* bit-parallel signature test of the 32 positions that start in word wi:
+        if (k + 1 < NSTEP) { /* next step's dwords: in flight across the barriers below */
+            const uint64_t wn = w_first + (uint64_t)(k + 1) * 256u + threadIdx.x;
+            w0 = wn < nrec32 ? rec32[wn] : 0u;
+            w1 = wn + 1 < nrec32 ? rec32[wn + 1] : 0u;
+        }
+        /* bit-parallel signature test of the 32 positions that start in this dword:
          *   bits 0..2 = 0,0,1 (BFINAL 0, BTYPE 2)   bits 8..12 = 1,0,0,0,0 (HDIST == 1)
-         *   HLIT = bits 3..7 <= 29  <=>  not (bits 4,5,6,7 all set) */
+         *   HLIT = bits 3..7 <= 29  <=>  not (bits 4,5,6,7 all set)
+         * Two positions less than 5 bits apart cannot both fit, so a dword queues at most 7. */
         const unsigned long long sig = ~win & ~(win >> 1) & (win >> 2) & (win >> 8) & ~(win >> 9) & ~(win >> 10) & ~(win >> 11) &
                                        ~(win >> 12) & ~((win >> 4) & (win >> 5) & (win >> 6) & (win >> 7));
         uint32_t hits = (uint32_t)sig;
         while (hits) {
             const int b = __builtin_ctz(hits);
             hits &= hits - 1u;
-            const uint64_t gp = (wi << 5) + (uint32_t)b;
+            const uint32_t slot = atomicAdd(&qn, 1u);
+            if (slot < (uint32_t)SCAN_QCAP) queue[slot] = (((uint32_t)k * 256u + threadIdx.x) << 5) | (uint32_t)b; /* bits from w_first */
+        }
+        __syncthreads();
+        const uint32_t pending = qn < (uint32_t)SCAN_QCAP ? qn : (uint32_t)SCAN_QCAP;
+        __syncthreads(); /* everyone has read qn before the next step adds to it: the branch below is uniform */
+        if (pending < 256u && k + 1 < NSTEP) continue;
+        for (uint32_t qi0 = threadIdx.x; qi0 < pending; qi0 += 256u) {
+            const uint64_t gp = (w_first << 5) + queue[qi0];
             if (gp < bit_lo || gp >= bit_hi) continue;
             const uint64_t p64 = gp - d.payoff * 8ull;
             if (p64 == 0 || p64 + 17u + 57u > paybits) continue;
@@ -1293,6 +1321,8 @@ __global__ __launch_bounds__(256) void k_scan_candidates(const uint8_t *__restri
             const uint32_t i = atomicAdd(nraw, 1u);
             if (i < rawcap) rawlist[i] = make_uint2(s, p); /* validated by k_validate_candidates */
         }
+        if (threadIdx.x == 0) qn = 0; /* nobody reads qn between the barrier above and the one below */
+        __syncthreads();
     }
 }
 
@@ -1307,63 +1337,109 @@ __device__ __forceinline__ uint32_t gbits(const uint8_t *rec, uint64_t reclen, u
     for (int k = 0; k < 4; k++) if (by + k < reclen) v |= (uint32_t)rec[by + k] << (8 * k);
     return (v >> (bit & 7u)) & ((1u << n) - 1u);
 }
-__global__ __launch_bounds__(256) void k_validate_candidates(const uint8_t *__restrict__ rec, uint64_t reclen,
-                                                             const DecStream *__restrict__ ds, const uint2 *__restrict__ rawlist,
-                                                             const uint32_t *__restrict__ nraw, uint32_t rawcap,
-                                                             Cand *__restrict__ cands, uint32_t *__restrict__ ncand)
+constexpr int VH_WORDS = 64; /* header dwords staged per candidate (a dynamic header of this codec is ~100 bytes) */
+__global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__restrict__ rec, uint64_t reclen,
+                                                            const DecStream *__restrict__ ds, const uint2 *__restrict__ rawlist,
+                                                            const uint32_t *__restrict__ nraw, uint32_t rawcap,
+                                                            Cand *__restrict__ cands, uint32_t *__restrict__ ncand)
 {
+    /* One candidate per lane.  A header is ~300 code-length symbols decoded one after the other; reading each from
+     * global memory made this kernel one long chain of dependent HBM/L2 round trips.  Each lane first copies its
+     * candidate's 256 bytes into its own LDS column (64 independent loads), then parses from there. */
+    __shared__ uint32_t hw[VH_WORDS * 64];
+    __shared__ uint8_t vlut[128 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
+    const uint64_t nrec32 = reclen >> 2;
     uint32_t total = *nraw;
     if (total > rawcap) total = rawcap;
-    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
+    for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < total; j += gridDim.x * 64) {
         const uint32_t s = rawlist[j].x, p = rawlist[j].y;
         const DecStream d = ds[s];
         const uint64_t g0 = d.payoff * 8ull + p;
         const uint32_t paybits = d.paylen * 8u;
+        const uint64_t wbase = g0 >> 5;
+#pragma unroll 8
+        for (int w = 0; w < VH_WORDS; w++) {
+            const uint64_t wi = wbase + (uint64_t)w;
+            uint32_t v = 0;
+            if (wi < nrec32) v = rec32[wi];
+            else if (wi * 4 < reclen) { /* ragged tail of the records buffer */
+                for (uint64_t k = wi * 4; k < reclen; k++) v |= (uint32_t)rec[k] << (8 * (k - wi * 4));
+            }
+            hw[w * 64 + lane] = v;
+        }
+        /* n <= 25 bits at global bit position g: from the lane's LDS column when staged, else from memory */
+        auto gbits = [&](const uint8_t *, uint64_t, uint64_t g, int n) -> uint32_t {
+            const uint64_t q = g - (wbase << 5);
+            const uint32_t i = (uint32_t)(q >> 5);
+            if (i + 1u < (uint32_t)VH_WORDS) {
+                const unsigned long long v = (unsigned long long)hw[i * 64 + lane] | ((unsigned long long)hw[(i + 1u) * 64 + lane] << 32);
+                return (uint32_t)(v >> (q & 31u)) & ((1u << n) - 1u);
+            }
+            return mrcz::gbits(rec, reclen, g, n);
+        };
         const uint32_t nlen = gbits(rec, reclen, g0 + 3, 5) + 257u, ndist = gbits(rec, reclen, g0 + 8, 5) + 1u;
         const uint32_t ncode = gbits(rec, reclen, g0 + 13, 4) + 4u;
         /* code-length code: canonical codes of <= 7 bits -> first-code/offset arrays in registers */
-        uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint8_t bl[19];
+        /* code-length code (<= 7 bits): canonical codes -> the lane's private 128-entry table in LDS (sym | len << 5).
+         * Per-length counters are 8-bit fields of one 64-bit register (no dynamically indexed register arrays). */
+        uint32_t bl[19];
+#pragma unroll
         for (int i = 0; i < 19; i++) bl[i] = 0;
-        for (uint32_t i = 0; i < ncode; i++) {
-            const uint32_t l = gbits(rec, reclen, g0 + 17 + 3u * i, 3);
-            bl[k_bl_order((int)i)] = (uint8_t)l;
-            cnt[l]++;
+        unsigned long long cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 19; i++) {
+            if ((uint32_t)i < ncode) {
+                const uint32_t l = gbits(rec, reclen, g0 + 17 + 3u * (uint32_t)i, 3);
+                bl[k_bl_order(i)] = l;
+                cnt += 1ull << (8u * l);
+            }
         }
-        cnt[0] = 0;
-        uint32_t first[8], offs[8], code = 0, idx0 = 0;
-        for (int l = 1; l <= 7; l++) { first[l] = code; offs[l] = idx0; code = (code + cnt[l]) << 1; idx0 += cnt[l]; }
-        uint8_t sorted[19];
+        unsigned long long next = 0; /* next code of each length */
+        uint32_t blkraft = 0;
         {
-            uint32_t cur[8];
-            for (int l = 0; l < 8; l++) cur[l] = 0;
-            for (int i = 0; i < 19; i++) if (bl[i]) { sorted[offs[bl[i]] + cur[bl[i]]] = (uint8_t)i; cur[bl[i]]++; }
+            uint32_t code = 0;
+#pragma unroll
+            for (int l = 1; l <= 7; l++) {
+                const uint32_t cprev = l == 1 ? 0u : (uint32_t)(cnt >> (8 * (l - 1))) & 0xffu;
+                code = (code + cprev) << 1;
+                next |= (unsigned long long)(code & 0xffu) << (8 * l);
+                blkraft += ((uint32_t)(cnt >> (8 * l)) & 0xffu) << (7 - l);
+            }
+        }
+        bool ok = nlen <= 286u && ndist <= 30u && blkraft == 128u; /* complete code: every table entry gets written */
+        if (ok) {
+#pragma unroll
+            for (int sym = 0; sym < 19; sym++) {
+                const uint32_t l = bl[sym];
+                if (l) {
+                    const uint32_t c = (uint32_t)(next >> (8u * l)) & 0xffu;
+                    next += 1ull << (8u * l);
+                    const uint32_t r = __brev(c) >> (32u - l);
+                    for (uint32_t k = r; k < 128u; k += 1u << l) vlut[k * 64u + (uint32_t)lane] = (uint8_t)((uint32_t)sym | (l << 5));
+                }
+            }
         }
         uint64_t pos = g0 + 17 + 3ull * ncode;
         const uint32_t total_l = nlen + ndist;
         uint32_t idx = 0, kraft = 0, prev = 0, eoblen = 0;
-        bool ok = nlen <= 286u && ndist <= 30u;
         while (ok && idx < total_l) {
             if (pos - d.payoff * 8ull + 14u > paybits) { ok = false; break; }
             const uint32_t v = gbits(rec, reclen, pos, 14);
-            /* canonical decode, MSB-first code accumulation */
-            uint32_t c = 0;
-            int l = 0, sym = -1;
-            for (l = 1; l <= 7; l++) {
-                c = (c << 1) | ((v >> (l - 1)) & 1u);
-                if (c - first[l] < cnt[l]) { sym = sorted[offs[l] + (c - first[l])]; break; }
-            }
-            if (sym < 0) { ok = false; break; }
-            pos += (uint32_t)l;
-            uint32_t rep = 1, val = (uint32_t)sym;
-            if (sym == 16) { if (idx == 0) { ok = false; break; } val = prev; rep = 3u + ((v >> l) & 3u); pos += 2; }
-            else if (sym == 17) { val = 0; rep = 3u + ((v >> l) & 7u); pos += 3; }
-            else if (sym == 18) { val = 0; rep = 11u + ((v >> l) & 127u); pos += 7; }
+            const uint32_t e = vlut[(v & 127u) * 64u + (uint32_t)lane];
+            const uint32_t l = e >> 5, sym = e & 31u;
+            pos += l;
+            uint32_t rep = 1, val = sym;
+            if (sym == 16u) { if (idx == 0) { ok = false; break; } val = prev; rep = 3u + ((v >> l) & 3u); pos += 2; }
+            else if (sym == 17u) { val = 0; rep = 3u + ((v >> l) & 7u); pos += 3; }
+            else if (sym == 18u) { val = 0; rep = 11u + ((v >> l) & 127u); pos += 7; }
             if (idx + rep > total_l) { ok = false; break; }
-            for (uint32_t k = 0; k < rep; k++) {
-                const uint32_t at = idx + k;
-                if (at < nlen) { if (val) kraft += 32768u >> val; if (at == 256u) eoblen = val; }
-            }
+            /* the lengths at [idx, idx + rep) that belong to the literal/length code */
+            const uint32_t lo = idx < nlen ? idx : nlen, hi = idx + rep < nlen ? idx + rep : nlen;
+            if (val) kraft += (hi - lo) * (32768u >> val);
+            if (lo <= 256u && 256u < hi) eoblen = val;
+            if (kraft > 32768u) { ok = false; break; } /* over-subscribed: no code */
             idx += rep;
             prev = val;
         }
