@@ -51,6 +51,8 @@ struct mrcz_ctx {
     uint32_t *candbase;
     BlkJob *jobs;
     uint8_t *ecache;       /* piece entries handed from k_blk_count to k_blk_write */
+    HdrCache *hdrs;        /* decoded dynamic headers, row = stream * MAXCAND + candidate slot */
+    uint32_t calltag;      /* changes with every decoded batch: stale header rows never match */
     uint32_t ecache_rows;
     uint2 *rawlist;        /* signature survivors awaiting full header validation */
     uint32_t rawcap;
@@ -130,6 +132,8 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->njobs, 4);
     ctx->ecache_rows = (uint32_t)(ns * (MAXBLK + MAXBLK / 4));
     if (e == hipSuccess) e = dalloc(&ctx->ecache, (size_t)ctx->ecache_rows * ECACHE_ROW);
+    if (e == hipSuccess) e = dalloc(&ctx->hdrs, ns * MAXCAND);
+    if (e == hipSuccess) e = hipMemset(ctx->hdrs, 0, ns * MAXCAND * sizeof(HdrCache));
     ctx->rawcap = (uint32_t)(ns * 16384u);
     if (e == hipSuccess) e = dalloc(&ctx->rawlist, ctx->rawcap);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counts, 4 * sizeof(uint32_t));
@@ -157,7 +161,7 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     (void)hipFree(ctx->tsum); (void)hipFree(ctx->tinfo); (void)hipFree(ctx->sinfo); (void)hipFree(ctx->blkstart);
     (void)hipFree(ctx->slideq); (void)hipFree(ctx->pairhist); (void)hipFree(ctx->blkfreq); (void)hipFree(ctx->blkcode);
     (void)hipFree(ctx->blkhdr); (void)hipFree(ctx->meta); (void)hipFree(ctx->lay); (void)hipFree(ctx->pairbits);
-    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobs); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->ecache); (void)hipFree(ctx->njobs);
+    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobs); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->ecache); (void)hipFree(ctx->hdrs); (void)hipFree(ctx->njobs);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts); (void)hipFree(ctx->dbgphase);
     (void)hipFree(ctx->planes);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
@@ -324,17 +328,18 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
             HIPCHK(hipMemsetAsync(ctx->fallback, 0xff, ns * sizeof(uint32_t), ctx->stream), "memset fallback");
         } else {
             /* block-parallel path: find block starts, size every candidate block, close the chains, write */
+            ctx->calltag = ctx->calltag * 0x01000193u + 0x9e3779b9u;
             LAUNCH("k_scan_candidates", k_scan_candidates, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(256), rec, len,
                    ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 1, ctx->rawcap);
             LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 1,
-                   ctx->rawcap, ctx->cands, ctx->ncand);
+                   ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag);
             LAUNCH("k_cand_index", k_cand_index, dim3(1), dim3(256), ctx->ncand, ns, ctx->candbase);
             HIPCHK(hipMemcpyAsync(ctx->h_counts, ctx->candbase + ns, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy ncand");
             HIPCHK(hipStreamSynchronize(ctx->stream), "sync (candidates)");
             const uint32_t total = ctx->h_counts[0];
             if (total)
                 LAUNCH_S("k_blk_count", k_blk_count, dim3(total), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ns, ctx->candbase,
-                         ctx->cands, ctx->planes, ctx->ecache, ctx->ecache_rows,
+                         ctx->cands, ctx->planes, ctx->ecache, ctx->ecache_rows, ctx->hdrs, ctx->calltag,
                          ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL);
             LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->candbase, ctx->jobs, ctx->njobs, ctx->fallback);
             HIPCHK(hipMemcpyAsync(ctx->h_counts + 1, ctx->njobs, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy njobs");
@@ -342,7 +347,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
             const uint32_t njobs = ctx->h_counts[1];
             if (njobs)
                 LAUNCH_S("k_blk_write", k_blk_write, dim3(njobs), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->jobs,
-                         ctx->fallback, ctx->planes, ctx->ecache, ctx->ecache_rows,
+                         ctx->fallback, ctx->planes, ctx->ecache, ctx->ecache_rows, ctx->hdrs, ctx->calltag,
                          ctx->phase_profile == 2 ? ctx->dbgphase + (size_t)4 * ctx->max_chunks * 20 : (unsigned long long *)NULL);
         }
         LAUNCH_S("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,

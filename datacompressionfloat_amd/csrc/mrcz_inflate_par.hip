@@ -907,13 +907,18 @@ __device__ __forceinline__ void hdr_lengths_block(ParShared &sh, int tid, uint32
     if (tid == 0 && ((sh.flag & 1u) || !(sh.flag & 2u) || tot < total)) sh.status = 2; /* sequential decoder re-parses */
 }
 
+/* Decoded dynamic header of one candidate block (row s * MAXCAND + slot of mrcz_ctx::hdrs).  Written by whoever
+ * parses the header first -- k_validate_candidates for every scanned candidate, the count pass for a stream's first
+ * block -- and read by the count and write passes, which then go straight to the table build.  `valid` holds a
+ * per-call tag mixed with the block's start bit, so rows of earlier calls never match and nothing needs clearing. */
 struct HdrCache {
     uint32_t valid, bfinal, nlen, ndist, cur_after, pad[3];
     uint8_t lens[320];
 };
+__device__ __forceinline__ uint32_t hdr_tag(uint32_t calltag, uint32_t bit) { return (calltag ^ (bit * 0x9e3779b1u)) | 1u; }
 constexpr int ECACHE_WINDOWS = 5; /* windows per block whose piece entries the count pass hands to the write pass */
 
-constexpr size_t ECACHE_ROW = (size_t)ECACHE_WINDOWS * PT + sizeof(HdrCache); /* bytes per candidate */
+constexpr size_t ECACHE_ROW = (size_t)ECACHE_WINDOWS * PT; /* bytes per candidate */
 
 struct StreamView {
     const uint8_t *rec;   /* chunk records of the batch */
@@ -949,12 +954,11 @@ __device__ __forceinline__ StreamView make_view(const uint8_t *rec, uint64_t rec
  * general-distance decoder.  All PT threads call it together. */
 template <bool WRITE>
 __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, const StreamView &sv, int tid, unsigned long long *dbg,
-                                                 uint8_t *ecache /* NULL, or ECACHE_WINDOWS x PT piece entries of this block */)
+                                                 uint8_t *ecache /* NULL, or ECACHE_WINDOWS x PT piece entries of this block */,
+                                                 HdrCache *hc /* NULL, or this block's decoded-header row */, uint32_t hctag)
 {
     uint32_t widx = 0; /* window number inside the block */
-    /* header cache: the count pass of a dynamic block hands its decoded code lengths to the write pass */
-    HdrCache *hc = ecache ? reinterpret_cast<HdrCache *>(ecache + (size_t)ECACHE_WINDOWS * PT) : nullptr;
-    const bool hdr_cached = WRITE && hc != nullptr && hc->valid == 0x600dcafeu;
+    const bool hdr_cached = hc != nullptr && hc->valid == hctag;
     if (hdr_cached) {
         if (tid == 0) { sh.btype = 2; sh.bfinal = hc->bfinal; sh.nlen = hc->nlen; sh.ndist = hc->ndist; sh.cur = hc->cur_after; }
         if (tid < 320) sh.lens[tid] = hc->lens[tid];
@@ -1015,7 +1019,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
         if (!WRITE && hc != nullptr) {
             if (sh.btype == 2) {
                 if (tid < 320) hc->lens[tid] = sh.lens[tid];
-                if (tid == 0) { hc->bfinal = sh.bfinal; hc->nlen = sh.nlen; hc->ndist = sh.ndist; hc->cur_after = sh.cur; hc->valid = 0x600dcafeu; }
+                if (tid == 0) { hc->bfinal = sh.bfinal; hc->nlen = sh.nlen; hc->ndist = sh.ndist; hc->cur_after = sh.cur; hc->valid = hctag; }
             } else if (tid == 0) hc->valid = 0;
         }
     }
@@ -1200,7 +1204,8 @@ struct Cand {
 struct BlkJob {
     uint32_t stream, bit, off, inlast;
     uint32_t cidx;   /* compact candidate index (row of the entry cache), 0xffffffff = none (stored block) */
-    uint32_t pad[3];
+    uint32_t hslot;  /* row of the header cache (stream * MAXCAND + candidate slot), 0xffffffff = none */
+    uint32_t pad[2];
 };
 
 /* RAW planes (zip.c:267-270): funnel-shifted dword copy from the (unaligned) payload */
@@ -1341,13 +1346,15 @@ constexpr int VH_WORDS = 64; /* header dwords staged per candidate (a dynamic he
 __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                             const DecStream *__restrict__ ds, const uint2 *__restrict__ rawlist,
                                                             const uint32_t *__restrict__ nraw, uint32_t rawcap,
-                                                            Cand *__restrict__ cands, uint32_t *__restrict__ ncand)
+                                                            Cand *__restrict__ cands, uint32_t *__restrict__ ncand,
+                                                            HdrCache *__restrict__ hdrs, uint32_t calltag)
 {
     /* One candidate per lane.  A header is ~300 code-length symbols decoded one after the other; reading each from
      * global memory made this kernel one long chain of dependent HBM/L2 round trips.  Each lane first copies its
      * candidate's 256 bytes into its own LDS column (64 independent loads), then parses from there. */
     __shared__ uint32_t hw[VH_WORDS * 64];
     __shared__ uint8_t vlut[128 * 64];
+    __shared__ uint8_t vlens[320 * 64]; /* decoded code lengths, one column per lane: handed to the count / write passes */
     const int lane = threadIdx.x;
     const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
     const uint64_t nrec32 = reclen >> 2;
@@ -1440,12 +1447,27 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
             if (val) kraft += (hi - lo) * (32768u >> val);
             if (lo <= 256u && 256u < hi) eoblen = val;
             if (kraft > 32768u) { ok = false; break; } /* over-subscribed: no code */
+            for (uint32_t k = 0; k < rep; k++) vlens[(idx + k) * 64u + (uint32_t)lane] = (uint8_t)val;
             idx += rep;
             prev = val;
         }
         if (ok && kraft == 32768u && eoblen != 0u) {
             const uint32_t i = atomicAdd(&ncand[s], 1u);
-            if (i < (uint32_t)MAXCAND) { Cand cnd; cnd.bit = p; cnd.end = 0; cnd.nout = 0; cnd.info = 0; cands[(size_t)s * MAXCAND + i] = cnd; }
+            if (i < (uint32_t)MAXCAND) {
+                Cand cnd; cnd.bit = p; cnd.end = 0; cnd.nout = 0; cnd.info = 0; cands[(size_t)s * MAXCAND + i] = cnd;
+                HdrCache *hc = hdrs + ((size_t)s * MAXCAND + i);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(hc->lens);
+                for (uint32_t k = 0; k < (total_l + 3u) / 4u; k++) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (uint32_t b = 0; b < 4u; b++)
+                        if (4u * k + b < total_l) w |= (uint32_t)vlens[(4u * k + b) * 64u + (uint32_t)lane] << (8u * b);
+                    dst[k] = w;
+                }
+                hc->bfinal = 0; hc->nlen = nlen; hc->ndist = ndist;
+                hc->cur_after = (uint32_t)(pos - d.payoff * 8ull);
+                hc->valid = hdr_tag(calltag, p);
+            }
         }
     }
 }
@@ -1470,7 +1492,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                                                   const DecStream *__restrict__ ds, uint32_t nstreams,
                                                   const uint32_t *__restrict__ candbase, Cand *__restrict__ cands,
                                                   uint8_t *__restrict__ planes, uint8_t *__restrict__ ecache, uint32_t ecache_rows,
-                                                  unsigned long long *__restrict__ dbg)
+                                                  HdrCache *__restrict__ hdrs, uint32_t calltag, unsigned long long *__restrict__ dbg)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
     ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
@@ -1489,7 +1511,8 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     if (tid == 0) { sh.cur = c->bit; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
     if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
     __syncthreads();
-    decode_one_block<false>(sh, stg, sv, tid, dbg, job < ecache_rows ? ecache + (size_t)job * ECACHE_ROW : nullptr);
+    decode_one_block<false>(sh, stg, sv, tid, dbg, job < ecache_rows ? ecache + (size_t)job * ECACHE_ROW : nullptr,
+                            hdrs + ((size_t)s * MAXCAND + ci), hdr_tag(calltag, c->bit));
     __syncthreads();
     if (tid == 0) {
         const bool ok = (sh.status == 0 || sh.status == 1) && sh.cur > c->bit;
@@ -1546,7 +1569,8 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
             BlkJob b;
             b.stream = s; b.bit = pos; b.off = off; b.inlast = last;
             b.cidx = found == 0xffffffffu ? 0xffffffffu : candbase[s] + found;
-            b.pad[0] = b.pad[1] = b.pad[2] = 0;
+            b.hslot = found == 0xffffffffu ? 0xffffffffu : s * (uint32_t)MAXCAND + found;
+            b.pad[0] = b.pad[1] = 0;
             jobs[j] = b;
         }
         off += c.nout;
@@ -1562,7 +1586,8 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
 __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_blk_write(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                   const DecStream *__restrict__ ds, const BlkJob *__restrict__ jobs,
                                                   const uint32_t *__restrict__ fallback, uint8_t *__restrict__ planes,
-                                                  uint8_t *__restrict__ ecache, uint32_t ecache_rows, unsigned long long *__restrict__ dbg)
+                                                  uint8_t *__restrict__ ecache, uint32_t ecache_rows, HdrCache *__restrict__ hdrs,
+                                                  uint32_t calltag, unsigned long long *__restrict__ dbg)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
     ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
@@ -1575,7 +1600,8 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     if (tid == 0) { sh.cur = job.bit; sh.op = job.off; sh.last = job.inlast; sh.haslit = 0; sh.status = 0; }
     if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
     __syncthreads();
-    decode_one_block<true>(sh, stg, sv, tid, dbg, job.cidx < ecache_rows ? ecache + (size_t)job.cidx * ECACHE_ROW : nullptr);
+    decode_one_block<true>(sh, stg, sv, tid, dbg, job.cidx < ecache_rows ? ecache + (size_t)job.cidx * ECACHE_ROW : nullptr,
+                           job.hslot != 0xffffffffu ? hdrs + job.hslot : nullptr, hdr_tag(calltag, job.bit));
     __syncthreads();
     if (dbg && tid == 0) for (int i = 0; i < 20; i++) atomicAdd(&dbg[(size_t)job.stream * 20 + i], sh.acc[i]);
 }
@@ -1604,7 +1630,7 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
         if (sh.status != 0) break;
         if (sh.op >= sv.n) { if (tid == 0) sh.status = 1; __syncthreads(); break; }
         if (dbg && tid == 0) sh.acc[10]++;
-        decode_one_block<true>(sh, stg, sv, tid, dbg, nullptr);
+        decode_one_block<true>(sh, stg, sv, tid, dbg, nullptr, nullptr, 0u);
         __syncthreads();
     }
     __syncthreads();
