@@ -506,30 +506,24 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
 
 /* Per-lane output packer of the write walk.  A lane's plane bytes are contiguous in HBM but start at any byte
  * address and come one token at a time; storing them byte by byte costs one scattered store instruction per
- * byte.  The packer collects them in a 64-bit register and stores aligned dwords; only the bytes of the lane's
- * first and last (partial) dword go out as byte stores, because those dwords are shared with the neighbouring
- * lanes' ranges. */
+ * byte.  The packer collects them in a 64-bit register and stores four at a time with ONE (generally unaligned)
+ * dword store -- gfx9 global memory takes unaligned dword accesses.  All lanes start empty, so in a literal run
+ * every lane of the wave flushes in the same iteration and the store instruction runs with a full exec mask. */
 struct OutPacker {
-    uint8_t *p;              /* dword-aligned address the low bytes of acc belong to */
-    unsigned long long acc;  /* pending bytes, byte j belongs at p[j] */
-    uint32_t fill;           /* bytes held in acc (the `head` dummy bytes included) */
-    uint32_t head;           /* bytes of the first dword that lie before the lane's range */
+    uint8_t *p;              /* where the low byte of acc goes */
+    unsigned long long acc;  /* pending bytes */
+    uint32_t fill;           /* bytes held in acc (< 4 between calls) */
 };
 __device__ __forceinline__ void pk_init(OutPacker &k, uint8_t *out)
 {
-    const uint32_t mis = (uint32_t)((uintptr_t)out & 3u);
-    k.p = out - mis;
+    k.p = out;
     k.acc = 0;
-    k.fill = mis;
-    k.head = mis;
+    k.fill = 0;
 }
+__device__ __forceinline__ void pk_store4(uint8_t *p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
 __device__ __forceinline__ void pk_flush_word(OutPacker &k)
 {
-    const uint32_t w = (uint32_t)k.acc;
-    if (k.head) {
-        for (uint32_t j = k.head; j < 4u; j++) k.p[j] = (uint8_t)(w >> (8u * j));
-        k.head = 0;
-    } else *reinterpret_cast<uint32_t *>(k.p) = w;
+    pk_store4(k.p, (uint32_t)k.acc);
     k.p += 4;
     k.acc >>= 32;
     k.fill -= 4u;
@@ -540,6 +534,13 @@ __device__ __forceinline__ void pk_put(OutPacker &k, uint32_t b)
     k.fill++;
     if (k.fill >= 4u) pk_flush_word(k);
 }
+__device__ __forceinline__ void pk_finish(OutPacker &k)
+{
+    for (uint32_t j = 0; j < k.fill; j++) k.p[j] = (uint8_t)(k.acc >> (8u * j));
+    k.p += k.fill;
+    k.acc = 0;
+    k.fill = 0;
+}
 /* `n` copies of byte b (a distance-1 match) */
 __device__ __forceinline__ void pk_run(OutPacker &k, uint32_t b, uint32_t n)
 {
@@ -547,6 +548,7 @@ __device__ __forceinline__ void pk_run(OutPacker &k, uint32_t b, uint32_t n)
     if (n >= 48u) {
         /* long run: byte-feed up to a 16-byte boundary, then whole 16-byte stores */
         while ((((uintptr_t)k.p + k.fill) & 15u) != 0u) { pk_put(k, b); n--; }
+        pk_finish(k);
         const uint32_t w = (uint32_t)pat;
         const uint4 v = make_uint4(w, w, w, w);
         for (; n >= 16u; n -= 16u) { *reinterpret_cast<uint4 *>(k.p) = v; k.p += 16; }
@@ -560,10 +562,6 @@ __device__ __forceinline__ void pk_run(OutPacker &k, uint32_t b, uint32_t n)
         n -= take;
         while (k.fill >= 4u) pk_flush_word(k);
     }
-}
-__device__ __forceinline__ void pk_finish(OutPacker &k)
-{
-    for (uint32_t j = k.head; j < k.fill; j++) k.p[j] = (uint8_t)(k.acc >> (8u * j));
 }
 
 /* P4 walk of one lane: decode its piece from `start` and write the plane bytes at `out` */
