@@ -50,10 +50,10 @@ struct mrcz_ctx {
     uint32_t *ncand;       /* [ns] candidate counts, then [ns + 1] prefix, then job counter */
     uint32_t *candbase;
     BlkJob *jobs;
-    uint8_t *ecache;       /* piece entries handed from k_blk_count to k_blk_write */
+    uint8_t *scratch;      /* speculatively decoded blocks wait here for their place in the plane; allocated on first use */
+    uint64_t scratch_bytes;
     HdrCache *hdrs;        /* decoded dynamic headers, row = stream * MAXCAND + candidate slot */
     uint32_t calltag;      /* changes with every decoded batch: stale header rows never match */
-    uint32_t ecache_rows;
     uint2 *rawlist;        /* signature survivors awaiting full header validation */
     uint32_t rawcap;
     uint32_t *njobs;
@@ -130,8 +130,6 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->candbase, ns + 1);
     if (e == hipSuccess) e = dalloc(&ctx->jobs, ns * MAXCAND);
     if (e == hipSuccess) e = dalloc(&ctx->njobs, 4);
-    ctx->ecache_rows = (uint32_t)(ns * (MAXBLK + MAXBLK / 4));
-    if (e == hipSuccess) e = dalloc(&ctx->ecache, (size_t)ctx->ecache_rows * ECACHE_ROW);
     if (e == hipSuccess) e = dalloc(&ctx->hdrs, ns * MAXCAND);
     if (e == hipSuccess) e = hipMemset(ctx->hdrs, 0, ns * MAXCAND * sizeof(HdrCache));
     ctx->rawcap = (uint32_t)(ns * 16384u);
@@ -144,7 +142,6 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     /* the parallel inflate keeps its window, tables and a 32 KiB output stage in LDS (> 64 KiB) */
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_inflate_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_blk_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_blk_write, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
     if (e != hipSuccess) {
         mrcz_destroy(ctx);
         return e == hipSuccess ? MRCZ_ENOMEM : MRCZ_ENOMEM;
@@ -161,7 +158,7 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     (void)hipFree(ctx->tsum); (void)hipFree(ctx->tinfo); (void)hipFree(ctx->sinfo); (void)hipFree(ctx->blkstart);
     (void)hipFree(ctx->slideq); (void)hipFree(ctx->pairhist); (void)hipFree(ctx->blkfreq); (void)hipFree(ctx->blkcode);
     (void)hipFree(ctx->blkhdr); (void)hipFree(ctx->meta); (void)hipFree(ctx->lay); (void)hipFree(ctx->pairbits);
-    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobs); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->ecache); (void)hipFree(ctx->hdrs); (void)hipFree(ctx->njobs);
+    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobs); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->scratch); (void)hipFree(ctx->hdrs); (void)hipFree(ctx->njobs);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts); (void)hipFree(ctx->dbgphase);
     (void)hipFree(ctx->planes);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
@@ -311,6 +308,13 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
     if (((uintptr_t)d_out & 15u) || ((uintptr_t)d_records & 3u)) return fail(ctx, MRCZ_EINVAL, "d_out must be 16-byte and d_records 4-byte aligned", hipSuccess);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     if (int rc = ensure_planes(ctx)) return rc;
+    if (!ctx->scratch) {
+        /* real blocks fill at most the planes' size; false candidates and 16-byte rounding get another half */
+        ctx->scratch_bytes = (uint64_t)6 * ctx->max_chunks * CHK;
+        if (ctx->scratch_bytes > 0xffffffffull * 16ull) ctx->scratch_bytes = 0xffffffffull * 16ull;
+        hipError_t e = hipMalloc((void **)&ctx->scratch, (size_t)ctx->scratch_bytes);
+        if (e != hipSuccess) { ctx->scratch = NULL; return fail(ctx, MRCZ_ENOMEM, "decode scratch", e); }
+    }
     const uint8_t *rec = (const uint8_t *)d_records;
     uint32_t *out = (uint32_t *)d_out;
     const uint64_t nchunks = (nfloats + chk - 1) / chk;
@@ -339,16 +343,15 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
             const uint32_t total = ctx->h_counts[0];
             if (total)
                 LAUNCH_S("k_blk_count", k_blk_count, dim3(total), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ns, ctx->candbase,
-                         ctx->cands, ctx->planes, ctx->ecache, ctx->ecache_rows, ctx->hdrs, ctx->calltag,
+                         ctx->cands, ctx->scratch, ctx->njobs + 2, (uint32_t)(ctx->scratch_bytes >> 4), ctx->hdrs, ctx->calltag,
                          ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL);
             LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->candbase, ctx->jobs, ctx->njobs, ctx->fallback);
             HIPCHK(hipMemcpyAsync(ctx->h_counts + 1, ctx->njobs, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy njobs");
             HIPCHK(hipStreamSynchronize(ctx->stream), "sync (chains)");
             const uint32_t njobs = ctx->h_counts[1];
             if (njobs)
-                LAUNCH_S("k_blk_write", k_blk_write, dim3(njobs), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->jobs,
-                         ctx->fallback, ctx->planes, ctx->ecache, ctx->ecache_rows, ctx->hdrs, ctx->calltag,
-                         ctx->phase_profile == 2 ? ctx->dbgphase + (size_t)4 * ctx->max_chunks * 20 : (unsigned long long *)NULL);
+                LAUNCH("k_blk_gather", k_blk_gather, dim3(njobs), dim3(256), rec, ctx->dstreams, ctx->jobs, ctx->cands, ctx->fallback,
+                       ctx->scratch, ctx->planes);
         }
         LAUNCH_S("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
                  ctx->fallback, ctx->phase_profile == 1 ? ctx->dbgphase : (unsigned long long *)NULL);

@@ -85,6 +85,9 @@ struct ParShared {
     uint32_t status;    /* 0 running, 1 done, 2 error, 3 needs the sequential decoder */
     uint32_t btype, bfinal, nlen, ndist;
     uint32_t flag;
+    uint32_t wbase;     /* scratch mode: 16-byte unit where this window's bytes go (0xffffffff = no room) */
+    uint32_t lead;      /* scratch mode: bytes the block produces before its first literal */
+    uint32_t nwin;      /* windows of the current block so far */
     unsigned long long acc[20], tp; /* phase counters (profiling builds of the call only) */
     uint32_t dmax;      /* longest distance code + extra bits of the current block */
     uint32_t mintok;    /* shortest literal/length code of the current block (every token is at least that long) */
@@ -204,46 +207,6 @@ __device__ __forceinline__ uint32_t base_dist_of(int dc) /* dc 0..29 */
 }
 
 
-/* ---- exit functions: 24 entries x 5 bits, entries 0..11 in lo, 12..23 in hi ---- */
-struct ExitFn {
-    unsigned long long lo, hi;
-};
-__device__ __forceinline__ uint32_t fn_get(const ExitFn &f, uint32_t e)
-{
-    const unsigned long long w = e < 12u ? f.lo : f.hi;
-    const uint32_t k = e < 12u ? e : e - 12u;
-    return (uint32_t)(w >> (5u * k)) & 31u;
-}
-__device__ __forceinline__ ExitFn fn_identity()
-{
-    ExitFn f;
-    f.lo = 0; f.hi = 0;
-    for (uint32_t e = 0; e < 12; e++) { f.lo |= (unsigned long long)e << (5 * e); f.hi |= (unsigned long long)(e + 12) << (5 * e); }
-    return f;
-}
-/* result[e] = second[first[e]]; 30/31 are absorbing.  Fully unrolled: the entry index is static,
- * only the lookup into `second` is a dynamic bit-field extract. */
-__device__ __forceinline__ ExitFn fn_compose(const ExitFn &first, const ExitFn &second)
-{
-    ExitFn r;
-    r.lo = 0; r.hi = 0;
-#pragma unroll
-    for (int e = 0; e < 12; e++) {
-        const uint32_t v = (uint32_t)(first.lo >> (5 * e)) & 31u;
-        const unsigned long long w = v < 12u ? second.lo : second.hi;
-        const unsigned long long o = v >= (uint32_t)MAXTOK ? (unsigned long long)v : ((w >> (5u * (v < 12u ? v : v - 12u))) & 31ull);
-        r.lo |= o << (5 * e);
-    }
-#pragma unroll
-    for (int e = 0; e < 12; e++) {
-        const uint32_t v = (uint32_t)(first.hi >> (5 * e)) & 31u;
-        const unsigned long long w = v < 12u ? second.lo : second.hi;
-        const unsigned long long o = v >= (uint32_t)MAXTOK ? (unsigned long long)v : ((w >> (5u * (v < 12u ? v : v - 12u))) & 31ull);
-        r.hi |= o << (5 * e);
-    }
-    return r;
-}
-
 __device__ __forceinline__ uint32_t huff_decode_lit(const ParShared &sh, uint32_t v)
 {
     const uint32_t e = sh.tok[v & ((1u << LBITS) - 1u)];
@@ -301,13 +264,14 @@ __device__ __forceinline__ uint32_t fast_token_entry(const ParShared &sh, uint32
     return t > (uint32_t)MAXTOK ? X_ERR : t;
 }
 
-/* P1 for blocks whose tokens are all >= 4 bits (every literal-heavy block): exit values of the piece that starts
- * at dword 8 * piece of the staged window, by a backward recurrence kept in LDS instead of registers:
+/* P1: exit values of the piece that starts at dword 8 * piece of the staged window, by a backward recurrence kept in
+ * LDS instead of registers:
  *     exit[k] = k + t >= 256 ? k + t - 256 : exit[k + t]          (t = bits of the token that starts at position k)
  * exit[] lives in the piece's column of ParShared::ring, indexed by k mod 32 (a token is at most 24 bits).  The
  * dynamic index costs one LDS read instead of a dozen VALU bit-field operations on a register-held table, and
- * this kernel is VALU-issue bound.  Four positions are handled together: with t >= 4 none of them can land on
- * another one of the same group, so their 4 + 4 LDS reads are independent. */
+ * this kernel is VALU-issue bound.  Four positions are handled together and their 4 + 4 LDS reads are independent:
+ * with t >= 4 (MIN4, every literal-heavy block) none of them can land on another one of the same group; otherwise
+ * the few in-group cases are patched from registers. */
 /* byte offset, inside ParShared::ring, of the exit value of position x (any x < 512) of piece 0 */
 __device__ __forceinline__ uint32_t ring_off(uint32_t x)
 {
@@ -315,7 +279,7 @@ __device__ __forceinline__ uint32_t ring_off(uint32_t x)
     static_assert(PT * 4 == 2048, "ring_off assumes 2 KiB rows");
     return (x * 0x201u) & 0x3803u;
 }
-template <bool TAIL>
+template <bool TAIL, bool MIN4>
 __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int wq, uint32_t lead)
 {
     /* the window is staged dword-aligned, its first token starts `lead` (< 32) bits in: funnel the piece's dwords
@@ -335,99 +299,34 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
             for (int j = 0; j < 4; j++)
                 if (tt[j] == 0u) tt[j] = token_bits(sh, w01 >> (4 * q + j));
         }
-        uint32_t packed = 0;
+        uint32_t ex[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t x = kbase + (uint32_t)(4 * q + j) + tt[j];
             const uint32_t r = col[ring_off(x)];
-            uint32_t ex = tt[j] >= X_ERR ? tt[j] : r;
-            if (TAIL) ex = (tt[j] < X_ERR && x >= (uint32_t)SUBBITS) ? x - (uint32_t)SUBBITS : ex;
-            packed |= ex << (8 * j);
+            ex[j] = tt[j] >= X_ERR ? tt[j] : r;
+            if (TAIL) ex[j] = (tt[j] < X_ERR && x >= (uint32_t)SUBBITS) ? x - (uint32_t)SUBBITS : ex[j];
         }
-        sh.ring[q][tid] = packed; /* positions kbase + 4q .. + 3 */
+        if (!MIN4) {
+            /* tokens shorter than 4 bits land inside this group of four, on a position whose exit is not in LDS yet:
+             * take it from the registers instead (highest position first; position 3 always lands beyond the group) */
+            if (tt[2] == 1u) ex[2] = ex[3];
+            if (tt[1] == 1u) ex[1] = ex[2];
+            if (tt[1] == 2u) ex[1] = ex[3];
+            if (tt[0] == 1u) ex[0] = ex[1];
+            if (tt[0] == 2u) ex[0] = ex[2];
+            if (tt[0] == 3u) ex[0] = ex[3];
+        }
+        sh.ring[q][tid] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (ex[3] << 24); /* positions kbase + 4q .. + 3 */
     }
 }
+template <bool MIN4>
 __device__ __forceinline__ void piece_exit_lds(ParShared &sh, uint32_t tid, uint32_t lead)
 {
-    piece_exit_word<true>(sh, tid, SUBBITS / 32 - 1, lead);
-    for (int wq = SUBBITS / 32 - 2; wq >= 0; wq--) piece_exit_word<false>(sh, tid, wq, lead);
+    piece_exit_word<true, MIN4>(sh, tid, SUBBITS / 32 - 1, lead);
+    for (int wq = SUBBITS / 32 - 2; wq >= 0; wq--) piece_exit_word<false, MIN4>(sh, tid, wq, lead);
 }
 
-/* P1: exit function of the piece [s, s + SUBBITS) of the staged window.  Positions are handled
- * backwards in groups of 8: the 8 table lookups of a group are independent (their LDS latency
- * overlaps), only the 5-bit shift-register update is a dependent chain. */
-template <bool MIN4>
-__device__ __forceinline__ ExitFn piece_exit_fn(const ParShared &sh, uint32_t s)
-{
-    unsigned long long lo = 0, hi = 0; /* entry d-1 = exit of position p+d */
-    for (int g = SUBBITS / 8 - 1; g >= 0; g--) {
-        const uint32_t p0 = s + 8u * (uint32_t)g;
-        const uint32_t wi = p0 >> 5, b0 = p0 & 31u;
-        const unsigned long long w01 = (unsigned long long)sh.win[wi] | ((unsigned long long)sh.win[wi + 1] << 32);
-        const unsigned long long w12 = (w01 >> 32) | ((unsigned long long)sh.win[wi + 2] << 32);
-        unsigned long long T = 0; /* 8 token codes, one byte each */
-        uint32_t slow = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t b = b0 + (uint32_t)j;
-            const unsigned long long v = b < 32u ? (w01 >> b) : (w12 >> (b - 32u));
-            const uint32_t tj = tok_bits(sh, (uint32_t)v & ((1u << LBITS) - 1u));
-            T |= (unsigned long long)tj << (8 * j);
-            slow |= (tj == 0u ? 1u : 0u) << j;
-        }
-        while (slow) { /* tokens the 10-bit table cannot size: one general decode per iteration */
-            const uint32_t j = (uint32_t)__builtin_ctz(slow);
-            slow &= slow - 1u;
-            const uint32_t b = b0 + j;
-            const uint32_t tj = token_bits(sh, b < 32u ? (w01 >> b) : (w12 >> (b - 32u)));
-            T |= (unsigned long long)tj << (8u * j);
-        }
-        if (MIN4) {
-            /* every token of this block is >= 4 bits: the four positions of a half group all land beyond it,
-             * so their four look-ups are independent and the shift register moves 4 entries (20 bits) at once */
-#pragma unroll
-            for (int h = 1; h >= 0; h--) {
-                unsigned long long ins = 0;
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const int j = 4 * h + 3 - m;
-                    const uint32_t k = 8u * (uint32_t)g + (uint32_t)j;
-                    const uint32_t tt = (uint32_t)(T >> (8 * j)) & 255u;
-                    unsigned long long ex;
-                    if (tt >= X_ERR) ex = tt;
-                    else if (k + tt >= (uint32_t)SUBBITS) ex = k + tt - (uint32_t)SUBBITS;
-                    else {
-                        const uint32_t e = tt - (uint32_t)m - 1u; /* >= 0 because tt >= 4 > m */
-                        const unsigned long long w = e < 12u ? lo : hi;
-                        ex = (w >> (5u * (e < 12u ? e : e - 12u))) & 31ull;
-                    }
-                    ins |= ex << (5 * (3 - m)); /* position j0 + 3 - m -> entry 3 - m ... entry 0 = lowest position */
-                }
-                hi = (hi << 20) | ((lo >> 40) & 0xfffffull);
-                lo = (lo << 20) | ins;
-            }
-        } else {
-    #pragma unroll
-            for (int j = 7; j >= 0; j--) {
-                const uint32_t k = 8u * (uint32_t)g + (uint32_t)j;
-                const uint32_t tt = (uint32_t)(T >> (8 * j)) & 255u;
-                unsigned long long ex;
-                if (tt >= X_ERR) ex = tt;
-                else if (k + tt >= (uint32_t)SUBBITS) ex = k + tt - (uint32_t)SUBBITS;
-                else {
-                    const uint32_t e = tt - 1u;
-                    const unsigned long long w = e < 12u ? lo : hi;
-                    ex = (w >> (5u * (e < 12u ? e : e - 12u))) & 31ull;
-                }
-                hi = ((hi << 5) | (lo >> 55)) & 0x0fffffffffffffffull;
-                lo = ((lo << 5) | ex) & 0x0fffffffffffffffull;
-            }
-        }
-        }
-    ExitFn f;
-    f.lo = lo; f.hi = hi;
-    return f;
-}
 
 /* RFC 1951 order in which code-length code lengths are stored */
 __device__ __forceinline__ int k_bl_order(int i)
@@ -449,7 +348,7 @@ struct SubResult {
 /* P3: count walk.  Decode tokens from window bit `start` until the position reaches `limit` (or
  * END_BLOCK), counting the plane bytes they produce.  Nearly every token is sized by the two fast
  * tables (token bits, produced bytes) with a single 12-bit lookup each. */
-template <bool TRACK_LAST>
+template <bool TRACK_LAST, bool STOP_AT_LIT = false>
 __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t start, uint32_t limit)
 {
     SubResult r;
@@ -465,6 +364,7 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
         const uint32_t e = sh.tok[idx];
         const uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
         if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) { /* 1 <= t <= MAXTOK, distance 1 */
+            if (STOP_AT_LIT && n == 1u) break;
             buf >>= t; nb -= (int)t; pos += t;
             r.nout += n;
             if (TRACK_LAST && n == 1u) r.lastlit = 0x100u | ((e >> TOK_SYM_SHIFT) & 0xffu);
@@ -475,6 +375,7 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
         if (d == 0xffffffffu) { r.flags |= F_ERR; break; }
         const int l = (int)(d >> 16);
         const uint32_t sym = d & 0xffffu;
+        if (STOP_AT_LIT && sym < 256u) break;
         buf >>= l; nb -= l; pos += (uint32_t)l;
         if (sym < 256u) {
             r.nout++;
@@ -914,9 +815,20 @@ struct HdrCache {
     uint8_t lens[320];
 };
 __device__ __forceinline__ uint32_t hdr_tag(uint32_t calltag, uint32_t bit) { return (calltag ^ (bit * 0x9e3779b1u)) | 1u; }
-constexpr int ECACHE_WINDOWS = 5; /* windows per block whose piece entries the count pass hands to the write pass */
+constexpr int CAND_WINDOWS = 5;   /* windows (32 KiB of compressed bits each) a speculatively decoded block may span */
 
-constexpr size_t ECACHE_ROW = (size_t)ECACHE_WINDOWS * PT; /* bytes per candidate */
+/* where a speculatively decoded block leaves its bytes: k_blk_count cannot know the block's place in the plane yet
+ * (that needs every earlier block's size), so each window takes a piece of a bump-allocated scratch buffer; once
+ * k_chain has placed the blocks, k_blk_gather moves the pieces with coalesced copies.  This replaces a second full
+ * decode of every block. */
+struct ScratchOut {
+    uint8_t *base;
+    uint32_t *top;    /* bump pointer, 16-byte units */
+    uint32_t cap16;
+    uint32_t *wbase;  /* [CAND_WINDOWS] of the candidate */
+    uint32_t *wlen;
+};
+enum { MODE_FINAL = 1, MODE_SCRATCH = 2 };
 
 struct StreamView {
     const uint8_t *rec;   /* chunk records of the batch */
@@ -950,12 +862,14 @@ __device__ __forceinline__ StreamView make_view(const uint8_t *rec, uint64_t rec
  * block, sh.op has advanced by the bytes produced, sh.last/sh.haslit hold the last byte produced, and
  * sh.status != 0 reports 1 = final block done, 2 = malformed / unsupported, 3 = needs the sequential
  * general-distance decoder.  All PT threads call it together. */
-template <bool WRITE>
+template <int MODE>
 __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, const StreamView &sv, int tid, unsigned long long *dbg,
-                                                 uint8_t *ecache /* NULL, or ECACHE_WINDOWS x PT piece entries of this block */,
+                                                 const ScratchOut &so /* MODE_SCRATCH only */,
                                                  HdrCache *hc /* NULL, or this block's decoded-header row */, uint32_t hctag)
 {
+    constexpr bool WRITE = MODE == MODE_FINAL;
     uint32_t widx = 0; /* window number inside the block */
+    if (tid == 0) { sh.nwin = 0; sh.lead = 0; }
     const bool hdr_cached = hc != nullptr && hc->valid == hctag;
     if (hdr_cached) {
         if (tid == 0) { sh.btype = 2; sh.bfinal = hc->bfinal; sh.nlen = hc->nlen; sh.ndist = hc->ndist; sh.cur = hc->cur_after; }
@@ -1022,7 +936,8 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
         }
     }
     if (sh.btype == 0) {
-        /* stored block: copy LEN bytes */
+        /* stored block: copy LEN bytes (the block-parallel path sizes and copies stored blocks elsewhere) */
+        if (MODE == MODE_SCRATCH) { if (tid == 0) sh.status = 2; __syncthreads(); return; }
         const uint32_t l = sh.nlen, op = sh.op;
         const uint32_t byte0 = sh.cur >> 3;
         if (op + l > sv.n || (uint64_t)byte0 + l > sv.paylen) { if (tid == 0) sh.status = 2; __syncthreads(); return; }
@@ -1077,20 +992,10 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
         const uint32_t pstart = wlead + (uint32_t)tid * SUBBITS;
         const uint32_t limit = pstart + SUBBITS;
         uint32_t entry;
-        const bool cached = WRITE && ecache != nullptr && widx < (uint32_t)ECACHE_WINDOWS;
-        if (cached) {
-            /* the count pass already resolved this window: entry offset of every piece, one byte each */
-            entry = ecache[(size_t)widx * PT + tid];
-        } else {
+        {
             /* P1: exit values of my piece -> my column of sh.ring (rows 0..23 = exit function) */
-            if (sh.mintok >= 4u) piece_exit_lds(sh, (uint32_t)tid, wlead);
-            else {
-                const ExitFn mine = piece_exit_fn<false>(sh, pstart);
-#pragma unroll
-                for (int r = 0; r < MAXTOK / 4; r++)
-                    sh.ring[r][tid] = fn_get(mine, 4u * r) | (fn_get(mine, 4u * r + 1u) << 8) | (fn_get(mine, 4u * r + 2u) << 16) |
-                                      (fn_get(mine, 4u * r + 3u) << 24);
-            }
+            if (sh.mintok >= 4u) piece_exit_lds<true>(sh, (uint32_t)tid, wlead);
+            else piece_exit_lds<false>(sh, (uint32_t)tid, wlead);
             PHASE(2);
             /* P2: resolve every piece's entry offset.  Composing whole functions (24 look-ups each) in a scan
              * is 24x redundant; instead the wave walks its 64 functions as a chain.  Pass 1: lane k < 24 of each
@@ -1125,7 +1030,6 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
                 if (k == i) entry = e;
                 if (e < (uint32_t)MAXTOK) e = hf[ring_off(e) + 4u * (uint32_t)i];
             }
-            if (!WRITE && ecache != nullptr && widx < (uint32_t)ECACHE_WINDOWS) ecache[(size_t)widx * PT + tid] = (uint8_t)entry;
         }
         widx++;
         const uint32_t start = entry < (uint32_t)MAXTOK ? pstart + entry : POS_INVALID;
@@ -1152,25 +1056,46 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
             __syncthreads();
             break;
         }
-        if (WRITE) {
-            /* P4: every lane walks its piece once more and writes its plane bytes straight to HBM: literals
-             * as bytes, distance-1 matches as fills of the last literal (wide aligned stores for long runs).
-             * A lane's output range is contiguous, lanes are independent, nothing is staged. */
-            const uint32_t lastin = sh.last; /* read before the scan's barriers: thread PT-1 rewrites it below */
-            const uint32_t before = block_excl_last_pt(active ? r.lastlit : 0u, sh.scan_b);
-            if (active && r.nout) write_walk(sh, start, limit, sv.out + op + myoff, before ? (before & 0xffu) : lastin);
-            PHASE(6);
-            if (tid == PT - 1) {
-                const uint32_t lw = (active && r.lastlit) ? r.lastlit : before;
-                if (lw) { sh.last = lw & 0xffu; sh.haslit = 1; }
+        /* P4: every lane walks its piece once more and writes its plane bytes straight to HBM: literals packed
+         * four to a store, distance-1 matches as fills of the last literal (wide aligned stores for long runs).
+         * A lane's output range is contiguous, lanes are independent, nothing is staged. */
+        uint8_t *wout;
+        const uint32_t haslit0 = sh.haslit; /* read before the scans' barriers: thread PT-1 rewrites it below */
+        const uint32_t lastin = sh.last;
+        if (MODE == MODE_SCRATCH) {
+            if (tid == 0) {
+                const uint32_t units = (total + 15u) >> 4;
+                uint32_t b16 = 0xffffffffu;
+                if (widx <= (uint32_t)CAND_WINDOWS) { /* widx already counts this window */
+                    b16 = units ? atomicAdd(so.top, units) : 0u;
+                    if (units && (b16 > so.cap16 || units > so.cap16 - b16)) b16 = 0xffffffffu;
+                    so.wbase[widx - 1u] = b16;
+                    so.wlen[widx - 1u] = total;
+                }
+                sh.wbase = b16;
+                sh.nwin = widx;
             }
-        } else {
-            /* count-only pass: remember the last literal (what a following block's leading match replicates) */
-            const uint32_t before = block_excl_last_pt(active ? r.lastlit : 0u, sh.scan_b);
-            if (tid == PT - 1) {
-                const uint32_t lw = (active && r.lastlit) ? r.lastlit : before;
-                if (lw) { sh.last = lw & 0xffu; sh.haslit = 1; }
+        }
+        const uint32_t before = block_excl_last_pt(active ? r.lastlit : 0u, sh.scan_b); /* contains barriers: sh.wbase is visible after it */
+        if (MODE == MODE_SCRATCH) {
+            if (sh.wbase == 0xffffffffu) { /* more windows than a candidate records, or the scratch buffer is full */
+                if (tid == 0) sh.status = 2;
+                __syncthreads();
+                break;
             }
+            wout = so.base + (size_t)sh.wbase * 16u + myoff;
+            if (!haslit0) {
+                /* the bytes in front of the block's first literal replicate the previous block's last byte, which is
+                 * not known here: remember how many there are, k_blk_gather fills them in */
+                const uint32_t fl = block_min_pt((active && r.lastlit) ? (uint32_t)tid : 0xffffffffu, sh.scan_a);
+                if ((uint32_t)tid == fl) sh.lead = op + myoff + count_walk<false, true>(sh, start, limit).nout;
+            }
+        } else wout = sv.out + op + myoff;
+        if (active && r.nout) write_walk(sh, start, limit, wout, before ? (before & 0xffu) : lastin);
+        PHASE(6);
+        if (tid == PT - 1) {
+            const uint32_t lw = (active && r.lastlit) ? r.lastlit : before;
+            if (lw) { sh.last = lw & 0xffu; sh.haslit = 1; }
         }
         if (tid == PT - 1) sh.op = op + total;
         if (e != 0xffffffffu) {
@@ -1198,12 +1123,16 @@ struct Cand {
     uint32_t end;    /* first bit after its END_BLOCK */
     uint32_t nout;   /* plane bytes it produces */
     uint32_t info;   /* bit 0 ok | bit 1 decoded | (0x100 | last byte) << 8 when it produced a literal */
+    uint32_t wbase[CAND_WINDOWS]; /* where each decoded window's bytes wait in the scratch buffer (16-byte units) */
+    uint32_t wlen[CAND_WINDOWS];  /* bytes of each window */
+    uint32_t nwin;   /* windows decoded */
+    uint32_t lead;   /* leading bytes that replicate the previous block's last byte */
 };
 struct BlkJob {
     uint32_t stream, bit, off, inlast;
-    uint32_t cidx;   /* compact candidate index (row of the entry cache), 0xffffffff = none (stored block) */
-    uint32_t hslot;  /* row of the header cache (stream * MAXCAND + candidate slot), 0xffffffff = none */
-    uint32_t pad[2];
+    uint32_t slot;     /* stream * MAXCAND + candidate slot; 0xffffffff = stored block */
+    uint32_t src, len; /* stored block: payload byte offset and length of its data */
+    uint32_t pad;
 };
 
 /* RAW planes (zip.c:267-270): funnel-shifted dword copy from the (unaligned) payload */
@@ -1489,9 +1418,11 @@ __global__ __launch_bounds__(256) void k_cand_index(const uint32_t *__restrict__
 __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_blk_count(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                   const DecStream *__restrict__ ds, uint32_t nstreams,
                                                   const uint32_t *__restrict__ candbase, Cand *__restrict__ cands,
-                                                  uint8_t *__restrict__ planes, uint8_t *__restrict__ ecache, uint32_t ecache_rows,
+                                                  uint8_t *__restrict__ scratch, uint32_t *__restrict__ scratch_top, uint32_t scratch_cap16,
                                                   HdrCache *__restrict__ hdrs, uint32_t calltag, unsigned long long *__restrict__ dbg)
 {
+    /* one workgroup per candidate block: decode it as if it were real, leave its bytes in the scratch buffer, record
+     * where it ends and how much it produced; k_chain then keeps the candidates that form the stream's chain */
     HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
     ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
     uint8_t *stg = reinterpret_cast<uint8_t *>(dynsm) + ((sizeof(ParShared) + 15u) & ~(size_t)15u);
@@ -1505,24 +1436,25 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     const uint32_t s = lo, ci = job - candbase[lo];
     Cand *c = &cands[(size_t)s * MAXCAND + ci];
     const DecStream d = ds[s];
-    const StreamView sv = make_view(rec, reclen, d, planes + (size_t)s * CHK);
+    const StreamView sv = make_view(rec, reclen, d, nullptr);
     if (tid == 0) { sh.cur = c->bit; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
     if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
     __syncthreads();
-    decode_one_block<false>(sh, stg, sv, tid, dbg, job < ecache_rows ? ecache + (size_t)job * ECACHE_ROW : nullptr,
-                            hdrs + ((size_t)s * MAXCAND + ci), hdr_tag(calltag, c->bit));
+    ScratchOut so;
+    so.base = scratch; so.top = scratch_top; so.cap16 = scratch_cap16; so.wbase = c->wbase; so.wlen = c->wlen;
+    decode_one_block<MODE_SCRATCH>(sh, stg, sv, tid, dbg, so, hdrs + ((size_t)s * MAXCAND + ci), hdr_tag(calltag, c->bit));
     __syncthreads();
     if (tid == 0) {
         const bool ok = (sh.status == 0 || sh.status == 1) && sh.cur > c->bit;
         c->end = sh.cur;
         c->nout = sh.op;
+        c->nwin = sh.nwin;
+        c->lead = sh.haslit ? sh.lead : sh.op; /* no literal at all: the whole block repeats the previous byte */
         if (dbg) for (int i = 0; i < 20; i++) atomicAdd(&dbg[(size_t)s * 20 + i], sh.acc[i]);
         c->info = (ok ? 1u : 0u) | 2u | (sh.haslit ? ((0x100u | (sh.last & 0xffu)) << 8) : 0u) | (sh.status == 1 ? 4u : 0u);
     }
 }
 
-/* D3: follow the chain of blocks of every stream from bit 0: a block is accepted only where the
- * previous one ended.  Emits one write job per block, or marks the stream for the sequential path. */
 __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, uint64_t reclen,
                                               const DecStream *__restrict__ ds, const Cand *__restrict__ cands,
                                               const uint32_t *__restrict__ ncand, const uint32_t *__restrict__ candbase,
@@ -1548,6 +1480,7 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
             if (b) { found = i0 + (uint32_t)__builtin_ctzll(b); break; }
         }
         Cand c;
+        uint32_t stored_src = 0;
         if (found == 0xffffffffu) {
             /* no dynamic-header candidate here: zlib stores incompressible blocks (typically the first and
              * the last block of a near-random plane); a stored block is sized from its LEN field directly */
@@ -1558,6 +1491,7 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
             const uint32_t l = gbits(rec, reclen, d.payoff * 8ull + db, 16), nl = gbits(rec, reclen, d.payoff * 8ull + db + 16, 16);
             if ((l ^ 0xffffu) != nl || (uint64_t)db + 32u + 8ull * l > (uint64_t)d.paylen * 8u) { fail = true; break; }
             c.bit = pos; c.end = db + 32u + 8u * l; c.nout = l;
+            stored_src = (db >> 3) + 4u;
             c.info = 3u | (l ? ((0x100u | (uint32_t)rec[d.payoff + (db >> 3) + 4u + l - 1u]) << 8) : 0u);
             if (l == 0u && off < d.n && c.end >= d.paylen * 8u) { fail = true; break; } /* only the sync marker is left */
         } else c = cs[found];
@@ -1566,9 +1500,8 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
             const uint32_t j = atomicAdd(njobs, 1u);
             BlkJob b;
             b.stream = s; b.bit = pos; b.off = off; b.inlast = last;
-            b.cidx = found == 0xffffffffu ? 0xffffffffu : candbase[s] + found;
-            b.hslot = found == 0xffffffffu ? 0xffffffffu : s * (uint32_t)MAXCAND + found;
-            b.pad[0] = b.pad[1] = 0;
+            b.slot = found == 0xffffffffu ? 0xffffffffu : s * (uint32_t)MAXCAND + found;
+            b.src = stored_src; b.len = c.nout; b.pad = 0;
             jobs[j] = b;
         }
         off += c.nout;
@@ -1577,36 +1510,51 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
         if ((c.info & 4u) && off < d.n) { fail = true; break; } /* a final block before the plane is complete */
     }
     if (!fail && off != d.n) fail = true;
-    if (lane == 0) fallback[s] = fail ? 1u : 0u; /* jobs of a failed stream are skipped by k_blk_write */
+    if (lane == 0) fallback[s] = fail ? 1u : 0u; /* jobs of a failed stream are skipped by k_blk_gather */
 }
 
 /* D4: decode the accepted blocks again, this time writing plane bytes at their final offsets */
-__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_blk_write(const uint8_t *__restrict__ rec, uint64_t reclen,
-                                                  const DecStream *__restrict__ ds, const BlkJob *__restrict__ jobs,
-                                                  const uint32_t *__restrict__ fallback, uint8_t *__restrict__ planes,
-                                                  uint8_t *__restrict__ ecache, uint32_t ecache_rows, HdrCache *__restrict__ hdrs,
-                                                  uint32_t calltag, unsigned long long *__restrict__ dbg)
+/* byte copy with arbitrary source and destination alignment: dwords where possible (gfx9 global memory takes
+ * unaligned dword accesses), bytes for the tail */
+__device__ __forceinline__ void wg_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int tid, int nthreads)
 {
-    HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
-    ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
-    uint8_t *stg = reinterpret_cast<uint8_t *>(dynsm) + ((sizeof(ParShared) + 15u) & ~(size_t)15u);
-    const int tid = threadIdx.x;
-    const BlkJob job = jobs[blockIdx.x];
-    if (fallback[job.stream]) return;
-    const DecStream d = ds[job.stream];
-    const StreamView sv = make_view(rec, reclen, d, planes + (size_t)job.stream * CHK);
-    if (tid == 0) { sh.cur = job.bit; sh.op = job.off; sh.last = job.inlast; sh.haslit = 0; sh.status = 0; }
-    if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
-    __syncthreads();
-    decode_one_block<true>(sh, stg, sv, tid, dbg, job.cidx < ecache_rows ? ecache + (size_t)job.cidx * ECACHE_ROW : nullptr,
-                           job.hslot != 0xffffffffu ? hdrs + job.hslot : nullptr, hdr_tag(calltag, job.bit));
-    __syncthreads();
-    if (dbg && tid == 0) for (int i = 0; i < 20; i++) atomicAdd(&dbg[(size_t)job.stream * 20 + i], sh.acc[i]);
+    const uint32_t nq = n >> 4; /* 16 bytes per lane and step */
+#pragma unroll 2
+    for (uint32_t i = (uint32_t)tid; i < nq; i += (uint32_t)nthreads) {
+        uint4 w;
+        __builtin_memcpy(&w, src + 16u * i, 16);
+        __builtin_memcpy(dst + 16u * i, &w, 16);
+    }
+    for (uint32_t i = 16u * nq + (uint32_t)tid; i < n; i += (uint32_t)nthreads) dst[i] = src[i];
 }
 
-/* Sequential-chain path (one workgroup walks all blocks of a stream): used for streams whose block
- * chain could not be closed from the candidates (stored / static / final blocks, truncated input) and
- * as the profiling vehicle of the per-block phases. */
+/* one workgroup per block of a closed chain: move the block's bytes to their place in the plane */
+__global__ __launch_bounds__(256) void k_blk_gather(const uint8_t *__restrict__ rec, const DecStream *__restrict__ ds,
+                                                    const BlkJob *__restrict__ jobs, const Cand *__restrict__ cands,
+                                                    const uint32_t *__restrict__ fallback, const uint8_t *__restrict__ scratch,
+                                                    uint8_t *__restrict__ planes)
+{
+    const BlkJob job = jobs[blockIdx.x];
+    if (fallback[job.stream]) return;
+    const int tid = threadIdx.x;
+    uint8_t *dst = planes + (size_t)job.stream * CHK + job.off;
+    if (job.slot == 0xffffffffu) { /* stored block: its bytes sit in the records */
+        wg_copy(dst, rec + ds[job.stream].payoff + job.src, job.len, tid, 256);
+        return;
+    }
+    const Cand &c = cands[job.slot];
+    uint32_t acc = 0;
+    for (uint32_t w = 0; w < c.nwin && w < (uint32_t)CAND_WINDOWS; w++) {
+        wg_copy(dst + acc, scratch + (size_t)c.wbase[w] * 16u, c.wlen[w], tid, 256);
+        acc += c.wlen[w];
+    }
+    const uint32_t lead = c.lead < c.nout ? c.lead : c.nout;
+    if (lead) {
+        __syncthreads(); /* the copies above wrote placeholders there */
+        for (uint32_t i = (uint32_t)tid; i < lead; i += 256u) dst[i] = (uint8_t)job.inlast;
+    }
+}
+
 __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                     const DecStream *__restrict__ ds, uint8_t *__restrict__ planes,
                                                     uint32_t *__restrict__ fallback, const uint32_t *__restrict__ only,
@@ -1628,7 +1576,7 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
         if (sh.status != 0) break;
         if (sh.op >= sv.n) { if (tid == 0) sh.status = 1; __syncthreads(); break; }
         if (dbg && tid == 0) sh.acc[10]++;
-        decode_one_block<true>(sh, stg, sv, tid, dbg, nullptr, nullptr, 0u);
+        decode_one_block<MODE_FINAL>(sh, stg, sv, tid, dbg, ScratchOut(), nullptr, 0u);
         __syncthreads();
     }
     __syncthreads();

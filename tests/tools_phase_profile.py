@@ -15,7 +15,7 @@ MODE = int(_s.argv[1]) if len(_s.argv) > 1 else 1   # 1 = sequential-chain kerne
 _LIB.mrcz_debug_inflate_phases(c._ctx, MODE, 0, None)
 out, _ = c.uncompress_device(rec, n)
 names = ["hdr", "stage", "P1 exitfn", "P2 compose", "P3 walk", "P3 scans", "P4 scatter", "P4 wait", "fill+flush", "-"]
-for s in ((4, 5, 6, 7) if MODE == 1 else (6, 7, 64 + 6, 64 + 7)):
+for s in ((4, 5, 6, 7) if MODE == 1 else (6, 7)):
     buf = (ctypes.c_uint64 * 20)()
     _LIB.mrcz_debug_inflate_phases(c._ctx, MODE, s, buf)
     v = list(buf)
