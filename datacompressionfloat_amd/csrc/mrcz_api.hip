@@ -350,7 +350,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
             HIPCHK(hipStreamSynchronize(ctx->stream), "sync (chains)");
             const uint32_t njobs = ctx->h_counts[1];
             if (njobs)
-                LAUNCH("k_blk_gather", k_blk_gather, dim3(njobs), dim3(256), rec, ctx->dstreams, ctx->jobs, ctx->cands, ctx->fallback,
+                LAUNCH("k_blk_gather", k_blk_gather, dim3(njobs, GATHER_PARTS), dim3(256), rec, ctx->dstreams, ctx->jobs, ctx->cands, ctx->fallback,
                        ctx->scratch, ctx->planes);
         }
         LAUNCH_S("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,

@@ -1514,21 +1514,37 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
 }
 
 /* D4: decode the accepted blocks again, this time writing plane bytes at their final offsets */
-/* byte copy with arbitrary source and destination alignment: dwords where possible (gfx9 global memory takes
- * unaligned dword accesses), bytes for the tail */
-__device__ __forceinline__ void wg_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int tid, int nthreads)
+/* byte copy with arbitrary source and destination alignment, shared by `parts` workgroups (this one is `part`):
+ * 16 bytes per lane and step (gfx9 global memory takes unaligned accesses), bytes for the tail.  The first `lead`
+ * bytes of the destination receive `fillb` instead of the source. */
+__device__ __forceinline__ void wg_copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lead, uint32_t fillb, int tid, uint32_t part,
+                                        uint32_t parts)
 {
-    const uint32_t nq = n >> 4; /* 16 bytes per lane and step */
+    const uint32_t nq = n >> 4;
+    const uint32_t fw = 0x01010101u * (fillb & 0xffu);
 #pragma unroll 2
-    for (uint32_t i = (uint32_t)tid; i < nq; i += (uint32_t)nthreads) {
+    for (uint32_t i = part * 256u + (uint32_t)tid; i < nq; i += 256u * parts) {
         uint4 w;
         __builtin_memcpy(&w, src + 16u * i, 16);
+        if (16u * i < lead) {
+            if (16u * i + 16u <= lead) w = make_uint4(fw, fw, fw, fw);
+            else {
+                uint8_t b[16];
+                __builtin_memcpy(b, &w, 16);
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; k++) if (16u * i + k < lead) b[k] = (uint8_t)fillb;
+                __builtin_memcpy(&w, b, 16);
+            }
+        }
         __builtin_memcpy(dst + 16u * i, &w, 16);
     }
-    for (uint32_t i = 16u * nq + (uint32_t)tid; i < n; i += (uint32_t)nthreads) dst[i] = src[i];
+    if (part == 0)
+        for (uint32_t i = 16u * nq + (uint32_t)tid; i < n; i += 256u) dst[i] = i < lead ? (uint8_t)fillb : src[i];
 }
 
-/* one workgroup per block of a closed chain: move the block's bytes to their place in the plane */
+/* GATHER_PARTS workgroups per block of a closed chain: move the block's bytes to their place in the plane (a block
+ * of an all-zero plane is megabytes long, a literal block 32 KiB: several workgroups share the long ones) */
+constexpr uint32_t GATHER_PARTS = 4;
 __global__ __launch_bounds__(256) void k_blk_gather(const uint8_t *__restrict__ rec, const DecStream *__restrict__ ds,
                                                     const BlkJob *__restrict__ jobs, const Cand *__restrict__ cands,
                                                     const uint32_t *__restrict__ fallback, const uint8_t *__restrict__ scratch,
@@ -1537,21 +1553,19 @@ __global__ __launch_bounds__(256) void k_blk_gather(const uint8_t *__restrict__ 
     const BlkJob job = jobs[blockIdx.x];
     if (fallback[job.stream]) return;
     const int tid = threadIdx.x;
+    const uint32_t part = blockIdx.y;
     uint8_t *dst = planes + (size_t)job.stream * CHK + job.off;
     if (job.slot == 0xffffffffu) { /* stored block: its bytes sit in the records */
-        wg_copy(dst, rec + ds[job.stream].payoff + job.src, job.len, tid, 256);
+        wg_copy(dst, rec + ds[job.stream].payoff + job.src, job.len, 0u, 0u, tid, part, GATHER_PARTS);
         return;
     }
     const Cand &c = cands[job.slot];
+    const uint32_t lead = c.lead < c.nout ? c.lead : c.nout; /* bytes that repeat the previous block's last byte */
     uint32_t acc = 0;
     for (uint32_t w = 0; w < c.nwin && w < (uint32_t)CAND_WINDOWS; w++) {
-        wg_copy(dst + acc, scratch + (size_t)c.wbase[w] * 16u, c.wlen[w], tid, 256);
-        acc += c.wlen[w];
-    }
-    const uint32_t lead = c.lead < c.nout ? c.lead : c.nout;
-    if (lead) {
-        __syncthreads(); /* the copies above wrote placeholders there */
-        for (uint32_t i = (uint32_t)tid; i < lead; i += 256u) dst[i] = (uint8_t)job.inlast;
+        const uint32_t len = c.wlen[w];
+        wg_copy(dst + acc, scratch + (size_t)c.wbase[w] * 16u, len, lead > acc ? lead - acc : 0u, job.inlast, tid, part, GATHER_PARTS);
+        acc += len;
     }
 }
 
