@@ -178,9 +178,9 @@ def main():
         codec.set_timing(False)
         dom = max(acc, key=acc.get)
         # algorithmic bytes of one launch: what the kernel must read once + write once
-        alg = {"k_tile_summary": 4.0 * nfloats, "k_histogram": 4.0 * nfloats, "k_emit": 4.0 * nfloats + zbytes,
-               "k_inflate_par": zbytes + 1.0 * nfloats * 4, "k_blk_count": 1.0 * zbytes, "k_blk_write": zbytes + 4.0 * nfloats,
-               "k_blk_decode": zbytes + 4.0 * nfloats, "k_merge_planes": 8.0 * nfloats}.get(dom, 4.0 * nfloats + zbytes)
+        alg = {"k_tile_summary": 8.0 * nfloats, "k_histogram": 4.0 * nfloats, "k_emit": 4.0 * nfloats + zbytes,
+               "k_blk_count": zbytes + 4.0 * nfloats, "k_blk_gather": 8.0 * nfloats, "k_inflate_par": zbytes + 4.0 * nfloats,
+               "k_merge_planes": 8.0 * nfloats}.get(dom, 4.0 * nfloats + zbytes)
         achieved = alg / (acc[dom] * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if the
