@@ -333,7 +333,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
         } else {
             /* block-parallel path: find block starts, size every candidate block, close the chains, write */
             ctx->calltag = ctx->calltag * 0x01000193u + 0x9e3779b9u;
-            LAUNCH("k_scan_candidates", k_scan_candidates, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(256), rec, len,
+            LAUNCH("k_scan_candidates", k_scan_candidates, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(64), rec, len,
                    ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 1, ctx->rawcap);
             LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 1,
                    ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag);

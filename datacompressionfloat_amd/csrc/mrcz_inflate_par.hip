@@ -1117,7 +1117,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
  * kernels
  * ==================================================================================== */
 constexpr int MAXCAND = 1024; /* block-start candidates kept per stream */
-constexpr int SCAN_QCAP = 256 + 7 * 256; /* k_scan_candidates: positions waiting for the second test (drained at 256; <= 7 per dword and step) */
+constexpr int SCAN_QCAP = 64 + 7 * 4 * 64; /* k_scan_candidates: positions waiting for the second test (drained at 64; <= 7 per dword, 4 dwords per lane and step) */
 struct Cand {
     uint32_t bit;    /* payload bit where a block (seems to) start */
     uint32_t end;    /* first bit after its END_BLOCK */
@@ -1165,18 +1165,20 @@ __global__ __launch_bounds__(PT) void k_raw_copy(const uint8_t *__restrict__ rec
  * depends on them (k_chain only accepts a candidate that the previous block's END_BLOCK lands on, and
  * any stream whose chain cannot be closed is decoded sequentially instead). */
 constexpr int SLAB_BYTES = 32768;
-__global__ __launch_bounds__(256) void k_scan_candidates(const uint8_t *__restrict__ rec, uint64_t reclen,
-                                                         const DecStream *__restrict__ ds, Cand *__restrict__ cands,
-                                                         uint32_t *__restrict__ ncand, uint2 *__restrict__ rawlist,
-                                                         uint32_t *__restrict__ nraw, uint32_t rawcap)
+__global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restrict__ rec, uint64_t reclen,
+                                                        const DecStream *__restrict__ ds, Cand *__restrict__ cands,
+                                                        uint32_t *__restrict__ ncand, uint2 *__restrict__ rawlist,
+                                                        uint32_t *__restrict__ nraw, uint32_t rawcap)
 {
+    /* one wave per 32 KiB slab of one stream's payload; no workgroup barriers anywhere */
     const uint32_t s = blockIdx.y;
     const DecStream d = ds[s];
     if (d.raw) return;
     const uint32_t slab0 = blockIdx.x * SLAB_BYTES;
     if (slab0 >= d.paylen) return;
     const uint32_t paybits = d.paylen * 8u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { /* the first block always starts at bit 0 */
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x == 0 && lane == 0) { /* the first block always starts at bit 0 */
         const uint32_t i = atomicAdd(&ncand[s], 1u);
         if (i < (uint32_t)MAXCAND) { Cand c; c.bit = 0; c.end = 0; c.nout = 0; c.info = 0; cands[(size_t)s * MAXCAND + i] = c; }
     }
@@ -1185,49 +1187,58 @@ __global__ __launch_bounds__(256) void k_scan_candidates(const uint8_t *__restri
     const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
     const uint64_t nrec32 = reclen >> 2;
     const uint64_t gbit0 = gbyte0 * 8ull;
-    /* Pass 1 (all lanes busy): in step k the 256 threads test, bit-parallel, the 32 positions that start in 256
+    /* Pass 1 (all lanes busy): in step k the 64 lanes test, bit-parallel, the 32 positions that start in 64
      * consecutive dwords, and only QUEUE the ~1/273 positions whose fixed header fields fit.  Pass 2 (drain, once
-     * 256 positions wait or the slab ends): one queued position per lane gets the code-length-code test, which
+     * 64 positions wait or the slab ends): one queued position per lane gets the code-length-code test, which
      * costs three more dependent loads.  Testing hits in place would make every wave pay that latency for the one
      * or two lanes that have a hit. */
     __shared__ uint32_t queue[SCAN_QCAP];
     __shared__ uint32_t qn;
-    if (threadIdx.x == 0) qn = 0;
-    __syncthreads();
-    const uint64_t w_first = gbit0 >> 5;           /* gbyte0 may be unaligned: positions are global bits */
+    if (lane == 0) qn = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t w_first = (gbit0 >> 5) & ~3ull; /* 16-byte aligned dword index at or before the slab (positions are global bits) */
     const uint64_t bit_lo = gbit0, bit_hi = gbit0 + 8ull * SLAB_BYTES;
-    constexpr int NSTEP = SLAB_BYTES / 4 / 256 + 1;
-    uint32_t w0, w1;
-    {
-        const uint64_t wi = w_first + threadIdx.x;
-        w0 = wi < nrec32 ? rec32[wi] : 0u;
-        w1 = wi + 1 < nrec32 ? rec32[wi + 1] : 0u;
-    }
+    constexpr int NSTEP = SLAB_BYTES / 16 / 64 + 1;
+    /* four dwords per lane and step (one 16-byte load + the dword after them): a step is one memory round trip, so
+     * the bytes in flight per wave decide how fast the slab goes by */
+    auto load5 = [&](uint64_t wi, uint32_t w[5]) {
+        if (wi + 5 <= nrec32) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(rec32 + wi);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            w[4] = rec32[wi + 4];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; j++) w[j] = wi + j < nrec32 ? rec32[wi + j] : 0u;
+        }
+    };
+    uint32_t wn[5];
+    load5(w_first + 4ull * lane, wn);
     for (int k = 0; k < NSTEP; k++) {
-        const unsigned long long win = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
-        if (k + 1 < NSTEP) { /* next step's dwords: in flight across the barriers below */
-            const uint64_t wn = w_first + (uint64_t)(k + 1) * 256u + threadIdx.x;
-            w0 = wn < nrec32 ? rec32[wn] : 0u;
-            w1 = wn + 1 < nrec32 ? rec32[wn + 1] : 0u;
+        uint32_t wc[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) wc[j] = wn[j];
+        if (k + 1 < NSTEP) load5(w_first + 4ull * ((uint64_t)(k + 1) * 64u + lane), wn); /* in flight while this step is tested */
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long win = (unsigned long long)wc[j] | ((unsigned long long)wc[j + 1] << 32);
+            /* bit-parallel signature test of the 32 positions that start in this dword:
+             *   bits 0..2 = 0,0,1 (BFINAL 0, BTYPE 2)   bits 8..12 = 1,0,0,0,0 (HDIST == 1)
+             *   HLIT = bits 3..7 <= 29  <=>  not (bits 4,5,6,7 all set)
+             * Two positions less than 5 bits apart cannot both fit, so a dword queues at most 7. */
+            const unsigned long long sig = ~win & ~(win >> 1) & (win >> 2) & (win >> 8) & ~(win >> 9) & ~(win >> 10) & ~(win >> 11) &
+                                           ~(win >> 12) & ~((win >> 4) & (win >> 5) & (win >> 6) & (win >> 7));
+            uint32_t hits = (uint32_t)sig;
+            while (hits) {
+                const int b = __builtin_ctz(hits);
+                hits &= hits - 1u;
+                const uint32_t slot = atomicAdd(&qn, 1u);
+                if (slot < (uint32_t)SCAN_QCAP) queue[slot] = ((((uint32_t)k * 64u + lane) * 4u + (uint32_t)j) << 5) | (uint32_t)b; /* bits from w_first */
+            }
         }
-        /* bit-parallel signature test of the 32 positions that start in this dword:
-         *   bits 0..2 = 0,0,1 (BFINAL 0, BTYPE 2)   bits 8..12 = 1,0,0,0,0 (HDIST == 1)
-         *   HLIT = bits 3..7 <= 29  <=>  not (bits 4,5,6,7 all set)
-         * Two positions less than 5 bits apart cannot both fit, so a dword queues at most 7. */
-        const unsigned long long sig = ~win & ~(win >> 1) & (win >> 2) & (win >> 8) & ~(win >> 9) & ~(win >> 10) & ~(win >> 11) &
-                                       ~(win >> 12) & ~((win >> 4) & (win >> 5) & (win >> 6) & (win >> 7));
-        uint32_t hits = (uint32_t)sig;
-        while (hits) {
-            const int b = __builtin_ctz(hits);
-            hits &= hits - 1u;
-            const uint32_t slot = atomicAdd(&qn, 1u);
-            if (slot < (uint32_t)SCAN_QCAP) queue[slot] = (((uint32_t)k * 256u + threadIdx.x) << 5) | (uint32_t)b; /* bits from w_first */
-        }
-        __syncthreads();
-        const uint32_t pending = qn < (uint32_t)SCAN_QCAP ? qn : (uint32_t)SCAN_QCAP;
-        __syncthreads(); /* everyone has read qn before the next step adds to it: the branch below is uniform */
-        if (pending < 256u && k + 1 < NSTEP) continue;
-        for (uint32_t qi0 = threadIdx.x; qi0 < pending; qi0 += 256u) {
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t pending = qn < (uint32_t)SCAN_QCAP ? qn : (uint32_t)SCAN_QCAP; /* one LDS read for the whole wave: uniform */
+        if (pending < 64u && k + 1 < NSTEP) continue;
+        for (uint32_t qi0 = lane; qi0 < pending; qi0 += 64u) {
             const uint64_t gp = (w_first << 5) + queue[qi0];
             if (gp < bit_lo || gp >= bit_hi) continue;
             const uint64_t p64 = gp - d.payoff * 8ull;
@@ -1253,8 +1264,9 @@ __global__ __launch_bounds__(256) void k_scan_candidates(const uint8_t *__restri
             const uint32_t i = atomicAdd(nraw, 1u);
             if (i < rawcap) rawlist[i] = make_uint2(s, p); /* validated by k_validate_candidates */
         }
-        if (threadIdx.x == 0) qn = 0; /* nobody reads qn between the barrier above and the one below */
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) qn = 0;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
