@@ -218,7 +218,7 @@ __device__ __forceinline__ uint32_t tok_bits(const ParShared &sh, uint32_t idx) 
 
 /* total bits of the token that starts at the low bit of v (>= 33 valid bits): 1..MAXTOK, or
  * X_EOB (END_BLOCK) / X_ERR (invalid, or a token the parallel path does not resolve) */
-__device__ __forceinline__ uint32_t token_bits(const ParShared &sh, unsigned long long v)
+__device__ __noinline__ uint32_t token_bits(const ParShared &sh, unsigned long long v)
 {
     const uint32_t d = huff_decode_lit(sh, (uint32_t)v);
     if (d == 0xffffffffu) return X_ERR;
@@ -287,25 +287,41 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
     const uint32_t *wp = sh.win + tid * (SUBBITS / 32) + (uint32_t)wq;
     const unsigned long long a01 = ((unsigned long long)wp[1] << 32) | wp[0], a12 = ((unsigned long long)wp[2] << 32) | wp[1];
     const unsigned long long w01 = ((a12 >> lead) << 32) | (uint32_t)(a01 >> lead);
+    const unsigned long long w01x4 = w01 << 2; /* index bits pre-scaled to the byte offset of a 4-byte table entry */
     const uint32_t kbase = 32u * (uint32_t)wq;
-    const uint8_t *col = reinterpret_cast<const uint8_t *>(&sh.ring[0][tid]);
+    const uint8_t *tokb = reinterpret_cast<const uint8_t *>(sh.tok);
+    const uint8_t *ringb = reinterpret_cast<const uint8_t *>(&sh.ring[0][0]);
+    const uint32_t lane4 = tid << 2; /* my column: bits 2..10 of a ring byte offset (row = bits 11..13, byte = bits 0..1) */
 #pragma unroll
     for (int q = 7; q >= 0; q--) {
         uint32_t tt[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) tt[j] = tok_bits(sh, (uint32_t)(w01 >> (4 * q + j)) & ((1u << LBITS) - 1u));
+        for (int j = 0; j < 4; j++) {
+            const int sft = 4 * q + j;
+            const uint32_t off = sft >= 2 ? (uint32_t)(w01 >> (sft - 2)) & (((1u << LBITS) - 1u) << 2)
+                                          : (uint32_t)(w01x4 >> sft) & (((1u << LBITS) - 1u) << 2);
+            tt[j] = tokb[off]; /* byte 0 of the entry: token bits */
+        }
         if ((tt[0] == 0u) | (tt[1] == 0u) | (tt[2] == 0u) | (tt[3] == 0u)) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (tt[j] == 0u) tt[j] = token_bits(sh, w01 >> (4 * q + j));
         }
-        uint32_t ex[4];
+        uint32_t ex[4], x[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t x = kbase + (uint32_t)(4 * q + j) + tt[j];
-            const uint32_t r = col[ring_off(x)];
-            ex[j] = tt[j] >= X_ERR ? tt[j] : r;
-            if (TAIL) ex[j] = (tt[j] < X_ERR && x >= (uint32_t)SUBBITS) ? x - (uint32_t)SUBBITS : ex[j];
+            x[j] = kbase + (uint32_t)(4 * q + j) + tt[j];
+            ex[j] = ringb[ring_off(x[j]) | lane4];
+        }
+        /* END_BLOCK / unresolvable tokens are rare: one test for the group instead of a select per position */
+        const uint32_t tmax = max(max(tt[0], tt[1]), max(tt[2], tt[3]));
+        if (tmax >= X_ERR) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) ex[j] = tt[j] >= X_ERR ? tt[j] : ex[j];
+        }
+        if (TAIL) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) ex[j] = (tt[j] < X_ERR && x[j] >= (uint32_t)SUBBITS) ? x[j] - (uint32_t)SUBBITS : ex[j];
         }
         if (!MIN4) {
             /* tokens shorter than 4 bits land inside this group of four, on a position whose exit is not in LDS yet:
