@@ -45,22 +45,27 @@ struct TreeMem {
 #define BLLEN(i) HEAP(64 + (i))
 #define BLCODE(i) HEAP(96 + (i))
 
-/* zlib's pqdownheap with the value to place passed in a register.  Both children are always read (the index of a
- * missing right child is clamped), so the two LDS reads of a level are independent. */
+/* zlib's pqdownheap with the value to place passed in a register.  The kernel's time is ONE tree's dependent
+ * instruction chain (a wave holds 48 trees and nothing else runs on its SIMD), so the loop is kept to the bare
+ * minimum: nodes are addressed by their element offset o = node * HT (child = 2 o, no multiplies), both children are
+ * always read (the offset of a missing right child is clamped) so the two LDS reads are independent, and
+ * smaller(a, b) = (a >> 10) <= (b >> 10) is evaluated as a <= (b | 1023). */
 __device__ __forceinline__ void sift_down(uint32_t *heap, int tid, int heap_len, int k, uint32_t v)
 {
-    int j = k << 1;
-    while (j <= heap_len) {
-        const int j1 = j < heap_len ? j + 1 : j;
-        uint32_t cj = heap[j * HT + tid];
-        const uint32_t cj1 = heap[j1 * HT + tid];
-        if (j1 != j && (cj1 >> 10) <= (cj >> 10)) { j = j1; cj = cj1; }
-        if ((v >> 10) <= (cj >> 10)) break;
-        heap[k * HT + tid] = cj;
-        k = j;
-        j <<= 1;
+    uint32_t *hp = heap + tid;
+    const int lim = heap_len * HT;
+    int a = k * HT, aj = a << 1;
+    while (aj <= lim) {
+        const int aj1 = aj < lim ? aj + HT : aj;
+        uint32_t cj = hp[aj];
+        const uint32_t cj1 = hp[aj1];
+        if (aj1 != aj && cj1 <= (cj | 1023u)) { aj = aj1; cj = cj1; }
+        if (v <= (cj | 1023u)) break;
+        hp[a] = cj;
+        a = aj;
+        aj <<= 1;
     }
-    heap[k * HT + tid] = v;
+    hp[a] = v;
 }
 
 /* heap holds n0 leaf keys (1-based).  Runs zlib's merge loop; returns the number of merges.  Merge i removes
