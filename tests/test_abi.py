@@ -16,7 +16,7 @@ LIB = os.path.join(util.ROOT, "datacompressionfloat_amd", "lib", "libmrcz_hip.so
 
 def _declared():
     src = open(HDR).read()
-    return sorted(set(re.findall(r"\b(mrcz_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(mrcz_[a-z0-9_]+)\s*\(", src)))
 
 
 @pytest.fixture(scope="module")
