@@ -844,20 +844,28 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
 
             /* pass A: bits produced by this lane.  The 64 table reads are independent (unrolled, bytes
              * come from registers), so their LDS latency overlaps; matches are rare and handled apart. */
+            if (__ballot(S != 0ull) == 0ull) { pos0 = pos1; continue; } /* no symbol starts in this part (inside long runs) */
             uint32_t lbits = 0;
             {
                 const uint64_t L = S & ~M;
                 const uint4 *row128 = reinterpret_cast<const uint4 *>(plane + lane * ROWPAD);
 #pragma unroll 1
                 for (int g = 0; g < 4; g++) { /* 16 positions per step: bounded register use, 16 reads in flight */
+                    const uint32_t Lg = (uint32_t)(L >> (16 * g)) & 0xffffu;
+                    const unsigned long long some = __ballot(Lg != 0u), notall = __ballot(Lg != 0xffffu);
+                    if (some == 0ull) continue; /* wave-uniform: nobody has a literal in this quarter */
                     const uint4 rw = row128[g];
                     const uint32_t wv[4] = {rw.x, rw.y, rw.z, rw.w};
-                    const uint32_t Lg = (uint32_t)(L >> (16 * g)) & 0xffffu;
+                    if (notall == 0ull) { /* everybody has 16 literals: no per-position tests */
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const uint32_t byte = (wv[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                        const uint32_t e = lut[byte];
-                        lbits += ((Lg >> j) & 1u) ? (e >> 16) : 0u;
+                        for (int j = 0; j < 16; j++) lbits += lut[(wv[j >> 2] >> (8 * (j & 3))) & 0xffu] >> 16;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const uint32_t byte = (wv[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                            const uint32_t e = lut[byte];
+                            lbits += ((Lg >> j) & 1u) ? (e >> 16) : 0u;
+                        }
                     }
                 }
                 uint64_t m = M;
@@ -883,9 +891,22 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
                     const uint4 *row128 = reinterpret_cast<const uint4 *>(plane + lane * ROWPAD);
 #pragma unroll 1
                     for (int g = 0; g < 4; g++) {
+                        const uint32_t Sg = (uint32_t)(S >> (16 * g)) & 0xffffu, Mg = (uint32_t)(M >> (16 * g)) & 0xffffu;
+                        if (__ballot(Sg != 0u) == 0ull) continue; /* wave-uniform: no symbol starts in this quarter */
                         const uint4 rw = row128[g];
                         const uint32_t wv[4] = {rw.x, rw.y, rw.z, rw.w};
-                        const uint32_t Sg = (uint32_t)(S >> (16 * g)) & 0xffffu, Mg = (uint32_t)(M >> (16 * g)) & 0xffffu;
+                        if (__ballot(Mg != 0u || Sg != 0xffffu) == 0ull) {
+                            /* literals only, for every lane (the interior of a coded plane): two codes (<= 15 bits
+                             * each) are joined in 32 bits and appended with one 64-bit shift */
+#pragma unroll
+                            for (int j = 0; j < 16; j += 2) {
+                                const uint32_t e0 = lut[(wv[j >> 2] >> (8 * (j & 3))) & 0xffu];
+                                const uint32_t e1 = lut[(wv[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xffu];
+                                const uint32_t n0 = e0 >> 16;
+                                packer_put(pk, (e0 & 0xffffu) | ((e1 & 0xffffu) << n0), (int)(n0 + (e1 >> 16)));
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int j = 0; j < 16; j++) {
                             const uint32_t byte = (wv[j >> 2] >> (8 * (j & 3))) & 0xffu;
