@@ -390,12 +390,35 @@ __global__ __launch_bounds__(64) void k_histogram(const uint8_t *__restrict__ pl
          * atomics are issued back to back instead of one dependent ctz / load / atomic chain per symbol */
         {
             const uint64_t L = S & ~M;
+            /* A plane with a handful of distinct values (exponent bytes) sends all 64 lanes' atomics of one
+             * instruction to two or three LDS addresses, which the LDS serialises.  Such tiles (tested on the lanes'
+             * first bytes) count per value in the wave first: the lanes that hold the first active lane's value are
+             * found with a ballot and that lane adds their number. */
+            const uint32_t b0 = x[0] & 0xffu;
+            const bool fewvalues = popc64(__ballot(b0 == (uint32_t)__shfl((int)b0, 0))) >= 16;
+            if (fewvalues) {
 #pragma unroll
-            for (int i = 0; i < 64; i++) {
-                if ((L >> i) & 1ull) {
-                    const uint32_t byte = (x[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                    uint32_t *r = ((inA >> i) & 1ull) ? rowA : rowB;
-                    atomicAdd(&r[byte], 1u);
+                for (int i = 0; i < 64; i++) {
+                    const bool lit = (L >> i) & 1ull;
+                    /* row B entries sit HROW words after row A */
+                    const uint32_t key = ((x[i >> 2] >> (8 * (i & 3))) & 0xffu) + (((inA >> i) & 1ull) ? 0u : (uint32_t)HROW);
+                    unsigned long long act = __ballot(lit);
+                    while (act) {
+                        const int leader = ctz64(act);
+                        const uint32_t kl = (uint32_t)__shfl((int)key, leader);
+                        const unsigned long long same = __ballot(lit && key == kl);
+                        if (lane == leader) atomicAdd(&rowA[kl], (uint32_t)popc64(same));
+                        act &= ~same;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 64; i++) {
+                    if ((L >> i) & 1ull) {
+                        const uint32_t byte = (x[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                        uint32_t *r = ((inA >> i) & 1ull) ? rowA : rowB;
+                        atomicAdd(&r[byte], 1u);
+                    }
                 }
             }
         }
