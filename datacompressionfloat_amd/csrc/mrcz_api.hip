@@ -49,7 +49,7 @@ struct mrcz_ctx {
     Cand *cands;           /* block-start candidates, MAXCAND per stream */
     uint32_t *ncand;       /* [ns] candidate counts, then [ns + 1] prefix, then job counter */
     uint32_t *candbase;
-    BlkJob *jobs;
+    BlkJob *jobs, *jobs_tmp;
     uint8_t *scratch;      /* speculatively decoded blocks wait here for their place in the plane; allocated on first use */
     uint64_t scratch_bytes;
     HdrCache *hdrs;        /* decoded dynamic headers, row = stream * MAXCAND + candidate slot */
@@ -129,7 +129,8 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->ncand, ns);
     if (e == hipSuccess) e = dalloc(&ctx->candbase, ns + 1);
     if (e == hipSuccess) e = dalloc(&ctx->jobs, ns * MAXCAND);
-    if (e == hipSuccess) e = dalloc(&ctx->njobs, 4);
+    if (e == hipSuccess) e = dalloc(&ctx->jobs_tmp, ns * MAXCAND);
+    if (e == hipSuccess) e = dalloc(&ctx->njobs, 4 + RAW_SEGS); /* [0] jobs, [2] scratch top, [4..] raw list segment counts */
     if (e == hipSuccess) e = dalloc(&ctx->hdrs, ns * MAXCAND);
     if (e == hipSuccess) e = hipMemset(ctx->hdrs, 0, ns * MAXCAND * sizeof(HdrCache));
     ctx->rawcap = (uint32_t)(ns * 16384u);
@@ -158,7 +159,7 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     (void)hipFree(ctx->tsum); (void)hipFree(ctx->tinfo); (void)hipFree(ctx->sinfo); (void)hipFree(ctx->blkstart);
     (void)hipFree(ctx->slideq); (void)hipFree(ctx->pairhist); (void)hipFree(ctx->blkfreq); (void)hipFree(ctx->blkcode);
     (void)hipFree(ctx->blkhdr); (void)hipFree(ctx->meta); (void)hipFree(ctx->lay); (void)hipFree(ctx->pairbits);
-    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobs); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->scratch); (void)hipFree(ctx->hdrs); (void)hipFree(ctx->njobs);
+    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobs); (void)hipFree(ctx->jobs_tmp); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->scratch); (void)hipFree(ctx->hdrs); (void)hipFree(ctx->njobs);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts); (void)hipFree(ctx->dbgphase);
     (void)hipFree(ctx->planes);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
@@ -325,7 +326,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
         LAUNCH("k_parse_records", k_parse_records, dim3(1), dim3(64), rec, len, bfl, chk, ctx->dstreams, ctx->result);
         const uint32_t ns = 4 * nb;
         HIPCHK(hipMemsetAsync(ctx->ncand, 0, ns * sizeof(uint32_t), ctx->stream), "memset ncand");
-        HIPCHK(hipMemsetAsync(ctx->njobs, 0, 4 * sizeof(uint32_t), ctx->stream), "memset njobs");
+        HIPCHK(hipMemsetAsync(ctx->njobs, 0, (4 + RAW_SEGS) * sizeof(uint32_t), ctx->stream), "memset njobs");
         if (ctx->phase_profile == 2) HIPCHK(hipMemsetAsync(ctx->dbgphase, 0, (size_t)ns * 40 * sizeof(unsigned long long), ctx->stream), "memset dbg");
         if (ctx->phase_profile == 1) {
             /* profiling vehicle: every stream through the sequential-chain kernel with phase counters */
@@ -334,8 +335,8 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
             /* block-parallel path: find block starts, size every candidate block, close the chains, write */
             ctx->calltag = ctx->calltag * 0x01000193u + 0x9e3779b9u;
             LAUNCH("k_scan_candidates", k_scan_candidates, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(64), rec, len,
-                   ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 1, ctx->rawcap);
-            LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 1,
+                   ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 4, ctx->rawcap);
+            LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 4,
                    ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag);
             LAUNCH("k_cand_index", k_cand_index, dim3(1), dim3(256), ctx->ncand, ns, ctx->candbase);
             HIPCHK(hipMemcpyAsync(ctx->h_counts, ctx->candbase + ns, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy ncand");
@@ -345,7 +346,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
                 LAUNCH_S("k_blk_count", k_blk_count, dim3(total), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ns, ctx->candbase,
                          ctx->cands, ctx->scratch, ctx->njobs + 2, (uint32_t)(ctx->scratch_bytes >> 4), ctx->hdrs, ctx->calltag,
                          ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL);
-            LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->candbase, ctx->jobs, ctx->njobs, ctx->fallback);
+            LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->candbase, ctx->jobs, ctx->jobs_tmp, ctx->njobs, ctx->fallback);
             HIPCHK(hipMemcpyAsync(ctx->h_counts + 1, ctx->njobs, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy njobs");
             HIPCHK(hipStreamSynchronize(ctx->stream), "sync (chains)");
             const uint32_t njobs = ctx->h_counts[1];

@@ -1133,7 +1133,11 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, co
  * kernels
  * ==================================================================================== */
 constexpr int MAXCAND = 1024; /* block-start candidates kept per stream */
-constexpr int SCAN_QCAP = 64 + 7 * 4 * 64; /* k_scan_candidates: positions waiting for the second test (drained at 64; <= 7 per dword, 4 dwords per lane and step) */
+constexpr int SCAN_QCAP = 7 * 4 * 64; /* k_scan_candidates: positions of one step waiting for the second test (<= 7 per dword, 4 dwords per lane) */
+/* Survivors of the scan go to one of RAW_SEGS segments of the raw list, each with its own counter: tens of thousands of
+ * returning atomics on ONE address serialise in L2 and cost more than the scan itself (measured 0.3 ms of 0.5). */
+constexpr uint32_t RAW_SEGS = 64;
+constexpr uint32_t SURV_CAP = 128; /* survivors a wave collects in LDS before it reserves list space */
 struct Cand {
     uint32_t bit;    /* payload bit where a block (seems to) start */
     uint32_t end;    /* first bit after its END_BLOCK */
@@ -1203,40 +1207,57 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
     const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
     const uint64_t nrec32 = reclen >> 2;
     const uint64_t gbit0 = gbyte0 * 8ull;
-    /* Pass 1 (all lanes busy): in step k the 64 lanes test, bit-parallel, the 32 positions that start in 64
-     * consecutive dwords, and only QUEUE the ~1/273 positions whose fixed header fields fit.  Pass 2 (drain, once
-     * 64 positions wait or the slab ends): one queued position per lane gets the code-length-code test, which
-     * costs three more dependent loads.  Testing hits in place would make every wave pay that latency for the one
-     * or two lanes that have a hit. */
+    /* Per step the wave takes 256 consecutive dwords (16 bytes per lane).  Test 1 (all lanes busy, bit-parallel): the
+     * fixed fields of a dynamic header, for the 32 positions that start in each dword; the ~1/273 positions that fit
+     * are only QUEUED.  Test 2 (one queued position per lane): a complete code-length code.  Its 64 bits come from
+     * the LDS copy of the step's dwords -- re-reading them from global memory (three scattered loads per hit) cost
+     * five times the whole streaming pass. */
     __shared__ uint32_t queue[SCAN_QCAP];
-    __shared__ uint32_t qn;
-    if (lane == 0) qn = 0;
+    __shared__ uint32_t stepw[256 + 8];
+    __shared__ uint32_t surv[SURV_CAP];
+    __shared__ uint32_t qn, sn;
+    if (lane == 0) { qn = 0; sn = 0; }
     __builtin_amdgcn_wave_barrier();
+    const uint32_t seg = (blockIdx.x * 7u + blockIdx.y) % RAW_SEGS, segcap = rawcap / RAW_SEGS;
+    /* hand the collected survivors to the raw list: one reservation for the whole wave */
+    auto flush_survivors = [&]() {
+        const uint32_t n = sn < SURV_CAP ? sn : SURV_CAP;
+        if (n == 0u) return;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&nraw[seg], n);
+        base = (uint32_t)__shfl((int)base, 0);
+        for (uint32_t i = lane; i < n; i += 64u)
+            if (base + i < segcap) rawlist[(size_t)seg * segcap + base + i] = make_uint2(s, surv[i]);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) sn = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
     const uint64_t w_first = (gbit0 >> 5) & ~3ull; /* 16-byte aligned dword index at or before the slab (positions are global bits) */
     const uint64_t bit_lo = gbit0, bit_hi = gbit0 + 8ull * SLAB_BYTES;
     constexpr int NSTEP = SLAB_BYTES / 16 / 64 + 1;
-    /* four dwords per lane and step (one 16-byte load + the dword after them): a step is one memory round trip, so
-     * the bytes in flight per wave decide how fast the slab goes by */
-    auto load5 = [&](uint64_t wi, uint32_t w[5]) {
-        if (wi + 5 <= nrec32) {
+    auto load4 = [&](uint64_t wi, uint32_t w[4]) {
+        if (wi + 4 <= nrec32) {
             const uint4 v = *reinterpret_cast<const uint4 *>(rec32 + wi);
             w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            w[4] = rec32[wi + 4];
         } else {
 #pragma unroll
-            for (int j = 0; j < 5; j++) w[j] = wi + j < nrec32 ? rec32[wi + j] : 0u;
+            for (int j = 0; j < 4; j++) w[j] = wi + j < nrec32 ? rec32[wi + j] : 0u;
         }
     };
-    uint32_t wn[5];
-    load5(w_first + 4ull * lane, wn);
+    uint32_t wn[4]; /* the next step's dwords are in flight while a step is tested */
+    load4(w_first + 4ull * lane, wn);
     for (int k = 0; k < NSTEP; k++) {
-        uint32_t wc[5];
+        uint32_t wc[4];
 #pragma unroll
-        for (int j = 0; j < 5; j++) wc[j] = wn[j];
-        if (k + 1 < NSTEP) load5(w_first + 4ull * ((uint64_t)(k + 1) * 64u + lane), wn); /* in flight while this step is tested */
+        for (int j = 0; j < 4; j++) wc[j] = wn[j];
+        load4(w_first + 4ull * ((uint64_t)(k + 1) * 64u + lane), wn); /* one step past the slab on the last turn: look-ahead only */
+        *reinterpret_cast<uint4 *>(&stepw[4u * lane]) = make_uint4(wc[0], wc[1], wc[2], wc[3]);
+        if (lane < 2u) *reinterpret_cast<uint4 *>(&stepw[256u + 4u * lane]) = make_uint4(wn[0], wn[1], wn[2], wn[3]);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const unsigned long long win = (unsigned long long)wc[j] | ((unsigned long long)wc[j + 1] << 32);
+            const uint32_t wnext = j < 3 ? wc[j < 3 ? j + 1 : 3] : stepw[4u * lane + 4u]; /* the next lane's (or step's) first dword */
+            const unsigned long long win = (unsigned long long)wc[j] | ((unsigned long long)wnext << 32);
             /* bit-parallel signature test of the 32 positions that start in this dword:
              *   bits 0..2 = 0,0,1 (BFINAL 0, BTYPE 2)   bits 8..12 = 1,0,0,0,0 (HDIST == 1)
              *   HLIT = bits 3..7 <= 29  <=>  not (bits 4,5,6,7 all set)
@@ -1248,24 +1269,27 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
                 const int b = __builtin_ctz(hits);
                 hits &= hits - 1u;
                 const uint32_t slot = atomicAdd(&qn, 1u);
-                if (slot < (uint32_t)SCAN_QCAP) queue[slot] = ((((uint32_t)k * 64u + lane) * 4u + (uint32_t)j) << 5) | (uint32_t)b; /* bits from w_first */
+                if (slot < (uint32_t)SCAN_QCAP) queue[slot] = ((4u * lane + (uint32_t)j) << 5) | (uint32_t)b; /* bit inside the step */
             }
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t pending = qn < (uint32_t)SCAN_QCAP ? qn : (uint32_t)SCAN_QCAP; /* one LDS read for the whole wave: uniform */
-        if (pending < 64u && k + 1 < NSTEP) continue;
-        for (uint32_t qi0 = lane; qi0 < pending; qi0 += 64u) {
-            const uint64_t gp = (w_first << 5) + queue[qi0];
+        const uint64_t step_bit0 = (w_first + (uint64_t)k * 256u) << 5;
+        for (uint32_t qr = 0; qr < pending; qr += 64u) {
+            if (qr && sn > SURV_CAP - 64u) flush_survivors(); /* wave-uniform (sn is read by the whole wave at once) */
+            const uint32_t qi0 = qr + lane;
+            if (qi0 >= pending) continue;
+            const uint32_t sp = queue[qi0];
+            const uint64_t gp = step_bit0 + sp;
             if (gp < bit_lo || gp >= bit_hi) continue;
             const uint64_t p64 = gp - d.payoff * 8ull;
             if (p64 == 0 || p64 + 17u + 57u > paybits) continue;
             const uint32_t p = (uint32_t)p64;
             /* code-length code: HCLEN + 4 lengths of 3 bits after the 17 header bits */
-            const uint64_t q = gp + 13u;
-            const uint64_t qi = q >> 5;
-            const uint32_t a0 = qi < nrec32 ? rec32[qi] : 0u, a1 = qi + 1 < nrec32 ? rec32[qi + 1] : 0u;
-            const uint32_t a2 = qi + 2 < nrec32 ? rec32[qi + 2] : 0u;
-            const uint32_t sh0 = (uint32_t)(q & 31u);
+            const uint32_t q = sp + 13u;
+            const uint32_t qi = q >> 5; /* <= 256: stepw holds 8 dwords past the step */
+            const uint32_t a0 = stepw[qi], a1 = stepw[qi + 1u], a2 = stepw[qi + 2u];
+            const uint32_t sh0 = q & 31u;
             const unsigned long long lo = ((unsigned long long)a0 | ((unsigned long long)a1 << 32)) >> sh0;
             const unsigned long long hi = sh0 ? ((unsigned long long)a2 << (64u - sh0)) : 0ull;
             unsigned long long bits = lo | hi;           /* 64 bits from q: HCLEN(4) then 3-bit lengths */
@@ -1277,13 +1301,15 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
                 if (l) { kraft += 128u >> l; nz++; }
             }
             if (kraft != 128u || nz < 2u) continue;
-            const uint32_t i = atomicAdd(nraw, 1u);
-            if (i < rawcap) rawlist[i] = make_uint2(s, p); /* validated by k_validate_candidates */
+            const uint32_t i = atomicAdd(&sn, 1u);
+            if (i < SURV_CAP) surv[i] = p; /* validated by k_validate_candidates */
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) qn = 0;
         __builtin_amdgcn_wave_barrier();
+        if (sn > SURV_CAP - 64u) flush_survivors(); /* a drain round adds at most 64: never overflows (wave-uniform) */
     }
+    flush_survivors();
 }
 
 /* D1b: one lane per signature survivor decodes the whole dynamic header sequentially (from HBM/L2)
@@ -1313,10 +1339,21 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
     const int lane = threadIdx.x;
     const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
     const uint64_t nrec32 = reclen >> 2;
-    uint32_t total = *nraw;
-    if (total > rawcap) total = rawcap;
+    /* the raw list comes in RAW_SEGS segments: flat index -> (segment, offset) through the counts' prefix sums */
+    __shared__ uint32_t segbase[RAW_SEGS + 1];
+    const uint32_t segcap = rawcap / RAW_SEGS;
+    if (lane == 0) {
+        uint32_t acc = 0;
+        for (uint32_t g = 0; g < RAW_SEGS; g++) { segbase[g] = acc; const uint32_t c = nraw[g]; acc += c < segcap ? c : segcap; }
+        segbase[RAW_SEGS] = acc;
+    }
+    __syncthreads();
+    const uint32_t total = segbase[RAW_SEGS];
     for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < total; j += gridDim.x * 64) {
-        const uint32_t s = rawlist[j].x, p = rawlist[j].y;
+        uint32_t g = 0;
+        for (uint32_t stp = RAW_SEGS / 2; stp; stp >>= 1) if (segbase[g + stp] <= j) g += stp;
+        const uint2 rl = rawlist[(size_t)g * segcap + (j - segbase[g])];
+        const uint32_t s = rl.x, p = rl.y;
         const DecStream d = ds[s];
         const uint64_t g0 = d.payoff * 8ull + p;
         const uint32_t paybits = d.paylen * 8u;
@@ -1486,7 +1523,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, uint64_t reclen,
                                               const DecStream *__restrict__ ds, const Cand *__restrict__ cands,
                                               const uint32_t *__restrict__ ncand, const uint32_t *__restrict__ candbase,
-                                              BlkJob *__restrict__ jobs,
+                                              BlkJob *__restrict__ jobs, BlkJob *__restrict__ jobs_tmp,
                                               uint32_t *__restrict__ njobs, uint32_t *__restrict__ fallback)
 {
     const uint32_t s = blockIdx.x;
@@ -1497,7 +1534,10 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
     bool fail = nc > (uint32_t)MAXCAND;
     if (nc > (uint32_t)MAXCAND) nc = MAXCAND;
     const Cand *cs = cands + (size_t)s * MAXCAND;
-    uint32_t pos = 0, off = 0, last = 0;
+    uint32_t pos = 0, off = 0, last = 0, nj = 0;
+    BlkJob *mine = jobs_tmp + (size_t)s * MAXCAND; /* the chain's jobs are collected here, then appended to the job list
+                                                    * with ONE reservation (a returning atomic per block on one counter
+                                                    * serialises all streams in L2) */
     for (uint32_t step = 0; !fail && off < d.n && step < (uint32_t)MAXCAND; step++) {
         /* the candidate that starts exactly at pos */
         uint32_t found = 0xffffffffu;
@@ -1525,20 +1565,27 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
         } else c = cs[found];
         if (off + c.nout > d.n || c.end <= pos) { fail = true; break; }
         if (lane == 0) {
-            const uint32_t j = atomicAdd(njobs, 1u);
             BlkJob b;
             b.stream = s; b.bit = pos; b.off = off; b.inlast = last;
             b.slot = found == 0xffffffffu ? 0xffffffffu : s * (uint32_t)MAXCAND + found;
             b.src = stored_src; b.len = c.nout; b.pad = 0;
-            jobs[j] = b;
+            mine[nj] = b;
         }
+        nj++;
         off += c.nout;
         if (c.info >> 8) last = (c.info >> 8) & 0xffu;
         pos = c.end;
         if ((c.info & 4u) && off < d.n) { fail = true; break; } /* a final block before the plane is complete */
     }
     if (!fail && off != d.n) fail = true;
-    if (lane == 0) fallback[s] = fail ? 1u : 0u; /* jobs of a failed stream are skipped by k_blk_gather */
+    if (lane == 0) fallback[s] = fail ? 1u : 0u; /* a failed stream is decoded by k_inflate_par instead */
+    if (!fail && nj) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(njobs, nj);
+        base = (uint32_t)__shfl((int)base, 0);
+        __builtin_amdgcn_wave_barrier(); /* lane 0's records are visible to the wave (same wave, in-order memory) */
+        for (uint32_t i = (uint32_t)lane; i < nj; i += 64u) jobs[base + i] = mine[i];
+    }
 }
 
 /* D4: decode the accepted blocks again, this time writing plane bytes at their final offsets */
