@@ -25,6 +25,10 @@ sim = util.load_sim()
 rec = sim.compress_records(words[lo:hi], 8, first_chunk) if hi > lo else b""
 t = torch.frombuffer(bytearray(rec), dtype=torch.uint8) if rec else torch.empty(0, dtype=torch.uint8)
 full, sizes = shard.gather_records(t, dist, dst=0)
+# the asynchronous form (what bench.py pipelines) must deliver the same bytes
+h = shard.gather_records_start(t, dist, dst=0)
+full2, sizes2 = h.wait()
+assert sizes2 == sizes and (rank != 0 or torch.equal(full2, full))
 if rank == 0:
     open(os.environ["OUTPUT"], "wb").write(full.numpy().tobytes())
     assert sizes[0] == len(rec) and len(sizes) == world
