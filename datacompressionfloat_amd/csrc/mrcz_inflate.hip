@@ -29,7 +29,7 @@ __global__ void k_parse_records(const uint8_t *__restrict__ rec, uint64_t len, u
                                 DecStream *__restrict__ ds, uint64_t *__restrict__ result /* [0] consumed, [1] error */)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint64_t off = 0;
+    uint64_t off = result[0]; /* where the previous batch of this call stopped (0 for the first) */
     uint64_t err = 0;
     const uint64_t nchunks = (nfloats + chk - 1) / chk;
     for (uint64_t c = 0; c < nchunks; c++) {
@@ -51,7 +51,7 @@ __global__ void k_parse_records(const uint8_t *__restrict__ rec, uint64_t len, u
         off = p;
     }
     result[0] = off;
-    result[1] = err;
+    if (err) result[1] = err; /* sticky across the batches of a call */
 }
 
 /* ---- sequential bit reader over global memory (lane 0 only) ---- */

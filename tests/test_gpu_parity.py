@@ -113,6 +113,20 @@ def test_chunk_boundaries(codec, oracle):
         _roundtrip(codec, oracle, w, 8)
 
 
+def test_batches_smaller_than_the_volume(codec):
+    """A volume of 5 chunks + tail through contexts whose batch is 2 chunks (three batches; the running record offset
+    and the chunk-header walk carry over on the device) gives the same bytes as one batch."""
+    n = 5 * util.CHUNK + 4321
+    w = util.gauss_words(n, seed=5)
+    small = type(codec)(0, max_batch_chunks=2)
+    z_big = codec.zip_bytes(w.tobytes(), 8)
+    assert small.zip_bytes(w.tobytes(), 8) == z_big
+    exp = util.erase_expected(w, 8).tobytes()
+    assert small.unzip_bytes(z_big) == exp
+    assert codec.unzip_bytes(z_big) == exp
+    small.close()
+
+
 def test_empty_and_invalid(codec):
     from datacompressionfloat_amd import MrczError
     assert codec.zip_bytes(b"", 0) == b""
