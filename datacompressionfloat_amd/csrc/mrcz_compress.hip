@@ -778,8 +778,16 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
         __builtin_amdgcn_wave_barrier();
         const uint8_t *plane = lds;
         const TileInfo tinf = tinfo[(size_t)s * TPS + (t0 / TILE)];
-        const LaneTile lt = analyse_lane(x, lane, len, tinf.B, tinf.F);
-        const LaneCls cls = classify_lane(lt.E, lt.a, lt.prevS, lt.nextS);
+        /* a RAW plane is copied verbatim: no run analysis (wave-uniform) */
+        LaneTile lt;
+        LaneCls cls;
+        if (!si.raw) {
+            lt = analyse_lane(x, lane, len, tinf.B, tinf.F);
+            cls = classify_lane(lt.E, lt.a, lt.prevS, lt.nextS);
+        } else {
+            lt.E = 0; lt.V = valid_mask(len, lane); lt.a = 64 * lane; lt.prevS = 0; lt.nextS = 0;
+            cls.S = 0; cls.M = 0;
+        }
 
         if (si.raw) {
             /* RAW plane (zip.c:184-190): the payload is the plane bytes themselves */
