@@ -262,7 +262,6 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
     uint8_t *out = (uint8_t *)d_out;
     if (int rc = ensure_planes(ctx)) return rc;
     HIPCHK(hipMemsetAsync(ctx->result, 0, 8 * sizeof(uint64_t), ctx->stream), "memset result");
-    HIPCHK(hipMemsetAsync(out, 0, (size_t)((bound + 3u) & ~3ull), ctx->stream), "memset output");
 
     for (uint64_t c0 = 0; c0 < nchunks; c0 += ctx->max_chunks) {
         const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
@@ -283,7 +282,9 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
         LAUNCH("k_pair_bits", k_pair_bits, dim3(SPS, ns), dim3(64), ctx->sinfo, ctx->lay, ctx->pairhist, ctx->blkcode, ctx->tinfo,
                ctx->pairbits);
         LAUNCH("k_pair_offsets", k_pair_offsets, dim3(ns), dim3(64), ctx->sinfo, ctx->lay, ctx->tinfo, ctx->pairbits, ctx->pairoff);
-        LAUNCH("k_container", k_container, dim3(1), dim3(256), ctx->sinfo, nb, out, ctx->result);
+        LAUNCH("k_container", k_container, dim3(1), dim3(256), ctx->sinfo, nb, out, ctx->result, 0);
+        LAUNCH("k_zero_records", k_zero_records, dim3(2048), dim3(256), out, ctx->result);
+        LAUNCH("k_container", k_container, dim3(1), dim3(256), ctx->sinfo, nb, out, ctx->result, 1);
         LAUNCH("k_emit", k_emit, dim3(SPS, nb, 4), dim3(64), ctx->planes, bfl, ctx->tinfo, ctx->sinfo, ctx->lay, ctx->blkstart,
                ctx->blkcode, ctx->pairoff, out);
         LAUNCH("k_emit_headers", k_emit_headers, dim3(MAXBLK + 1, ns), dim3(64), ctx->sinfo, ctx->lay, ctx->meta, ctx->blkhdr,

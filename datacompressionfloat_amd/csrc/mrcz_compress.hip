@@ -644,9 +644,28 @@ __global__ __launch_bounds__(64) void k_pair_offsets(const StreamInfo *__restric
 /* ======================================================================================
  * container layout: payload offsets + the 16-byte chunk headers (workers.c:837-842, zip.c:381-391)
  * ==================================================================================== */
-__global__ __launch_bounds__(256) void k_container(StreamInfo *__restrict__ sinfo, uint32_t nchunks, uint8_t *__restrict__ out,
-                                                   uint64_t *__restrict__ result /* [0] running byte offset, [1..4] per-plane zfsz */)
+/* zero the records of this batch, bytes [result[5], result[0]) of the output (rounded up at the end only: what lies
+ * before belongs to the previous batch): the emit kernels OR their bit strings into it.  Clearing exactly what the
+ * batch produced instead of the whole mrcz_records_bound() halves the bytes written up front. */
+__global__ __launch_bounds__(256) void k_zero_records(uint8_t *__restrict__ out, const uint64_t *__restrict__ result)
 {
+    uint8_t *b = out + result[5], *e = out + result[0];
+    uint8_t *ba = reinterpret_cast<uint8_t *>(((uintptr_t)b + 15u) & ~(uintptr_t)15u);
+    uint8_t *ea = reinterpret_cast<uint8_t *>(((uintptr_t)e + 15u) & ~(uintptr_t)15u); /* the buffer has 64 spare bytes */
+    if (ba > ea) ba = ea;
+    if (blockIdx.x == 0 && threadIdx.x < 16u && b + threadIdx.x < ba) b[threadIdx.x] = 0;
+    uint4 *p = reinterpret_cast<uint4 *>(ba);
+    const uint64_t n = (uint64_t)(ea - ba) >> 4;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) p[i] = z;
+}
+
+__global__ __launch_bounds__(256) void k_container(StreamInfo *__restrict__ sinfo, uint32_t nchunks, uint8_t *__restrict__ out,
+                                                   uint64_t *__restrict__ result /* [0] running byte offset, [1..4] per-plane zfsz, [5] where this batch starts */,
+                                                   int write_headers)
+{
+    /* called twice per batch: write_headers = 0 lays the batch out (payload offsets, running offset), then the
+     * records are zeroed, then write_headers = 1 stores the 16-byte chunk headers */
     /* one thread per chunk of the batch (<= 128 chunks, records < 4 GiB) */
     __shared__ SegPair wsum[4];
     const uint32_t c = threadIdx.x;
@@ -661,24 +680,27 @@ __global__ __launch_bounds__(256) void k_container(StreamInfo *__restrict__ sinf
         }
         v.sum = 16u + len[0] + len[1] + len[2] + len[3];
     }
-    const uint64_t base = result[0];
+    const uint64_t base = write_headers ? result[5] : result[0];
     const SegPair pre = block_excl_scan(v, wsum);
     if (c < nchunks) {
         const uint64_t off = base + pre.sum;
         uint64_t p = off + 16;
         for (int j = 0; j < 4; j++) {
-            uint8_t *h = out + off + 4u * j;   /* pack_header, zip.c:381-391 */
-            h[0] = (uint8_t)(len[j] & 0xff);
-            h[1] = (uint8_t)((len[j] >> 8) & 0xff);
-            h[2] = (uint8_t)((len[j] >> 16) & 0xff);
-            h[3] = (uint8_t)(((len[j] >> 24) & 0x7f) | (raw[j] << 7));
-            sinfo[4 * c + j].payoff = p;
+            if (write_headers) {
+                uint8_t *h = out + off + 4u * j;   /* pack_header, zip.c:381-391 */
+                h[0] = (uint8_t)(len[j] & 0xff);
+                h[1] = (uint8_t)((len[j] >> 8) & 0xff);
+                h[2] = (uint8_t)((len[j] >> 16) & 0xff);
+                h[3] = (uint8_t)(((len[j] >> 24) & 0x7f) | (raw[j] << 7));
+            } else {
+                sinfo[4 * c + j].payoff = p;
+                atomicAdd((unsigned long long *)&result[1 + j], (unsigned long long)len[j] + 4ull);
+            }
             p += len[j];
-            atomicAdd((unsigned long long *)&result[1 + j], (unsigned long long)len[j] + 4ull);
         }
     }
     __syncthreads();
-    if (c + 1 == nchunks) result[0] = base + pre.sum + v.sum;
+    if (!write_headers && c + 1 == nchunks) { result[5] = base; result[0] = base + pre.sum + v.sum; }
 }
 
 /* ======================================================================================
