@@ -589,12 +589,11 @@ __device__ __forceinline__ uint32_t stage_bits(uint32_t *dst, int nwords, const 
 }
 
 /* The code lengths of a dynamic block (RFC 1951 3.2.7) are themselves a Huffman + run-length coded
- * sequence of up to 316 symbols.  Wave 0 resolves it with the same exact machinery as the block body,
- * in miniature and without any barrier: 64 pieces of 72 bits, 4-bit exit functions (a code-length
- * token is at most 7 + 7 bits) in one 64-bit register, a Kogge-Stone composition, a count walk, a
- * wave scan, a write walk.  The sequence has no end marker: it stops when nlen + ndist lengths have
- * been produced, so pieces past the end simply decode garbage that is never used. */
-constexpr int HB = 72; /* header bits per lane */
+ * sequence of up to 316 symbols.  When no validated header is at hand (a stream's first block, the sequential-chain
+ * fallback) the workgroup resolves it with the same exact machinery as the block body, in miniature: pieces of a few
+ * bits, 4-bit exit functions (a code-length token is at most 7 + 7 bits) in one 64-bit register, a composition scan,
+ * a count walk, a scan, a write walk.  The sequence has no end marker: it stops when nlen + ndist lengths have been
+ * produced, so pieces past the end simply decode garbage that is never used. */
 
 __device__ __forceinline__ uint32_t hdr_peek14(const ParShared &sh, uint32_t p)
 {
@@ -615,112 +614,9 @@ __device__ __forceinline__ uint32_t hdr_token(const ParShared &sh, uint32_t v)
     return (bl + 7u) | ((11u + ((v >> bl) & 127u)) << 8) | (2u << 16);
 }
 
-__device__ __forceinline__ void hdr_lengths_wave0(ParShared &sh, int lane, uint32_t cur, uint32_t lead, bool prof)
-{
-#define HPH(i) do { if (prof && lane == 0) { const unsigned long long n_ = (unsigned long long)clock64(); sh.acc[i] += n_ - sh.tp; sh.tp = n_; } } while (0)
-    const uint32_t hbase = sh.hpos + 3u * sh.ncode;
-    const uint32_t total = sh.nlen + sh.ndist;
-    const uint32_t ps = hbase + (uint32_t)(HB * lane);
-    /* exit function of my 72-bit piece: entry d-1 = exit of position p+d, 4 bits, 15 = invalid.
-     * Three groups of 24 positions; each group's 38 bits are cut out of the LDS words once, then the
-     * 24 table lookups are independent (unrolled) and only the shift-register update is a chain. */
-    unsigned long long E = 0;
-    for (int g = 2; g >= 0; g--) {
-        const uint32_t p0 = ps + 24u * (uint32_t)g;
-        const uint32_t wi = p0 >> 5, b0 = p0 & 31u;
-        const unsigned long long w01 = (unsigned long long)sh.win[wi] | ((unsigned long long)sh.win[wi + 1] << 32);
-        const unsigned long long w12 = (w01 >> 32) | ((unsigned long long)sh.win[wi + 2] << 32);
-        /* chunk bit j = stream bit p0 + j, j in [0, 64): b0 + 38 <= 69, so splice at the word boundary */
-        const unsigned long long chunk = b0 ? ((w01 >> b0) | ((w12 >> 32) << (64u - b0))) : w01;
-        uint32_t tk[24];
-#pragma unroll
-        for (int j = 0; j < 24; j++) tk[j] = hdr_token(sh, (uint32_t)(chunk >> j) & 0x3fffu);
-#pragma unroll
-        for (int j = 23; j >= 0; j--) {
-            const uint32_t k = 24u * (uint32_t)g + (uint32_t)j;
-            const uint32_t t = tk[j] & 255u;
-            unsigned long long ex;
-            if (!tk[j]) ex = 15;
-            else if (k + t >= (uint32_t)HB) ex = k + t - (uint32_t)HB;
-            else ex = (E >> (4u * (t - 1u))) & 15ull;
-            E = (E << 4) | ex;
-        }
-    }
-    HPH(17);
-    /* inclusive composition over the lanes */
-    unsigned long long inc = E;
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const unsigned long long y = __shfl_up(inc, dd);
-        if (lane >= dd) {
-            unsigned long long r = 0;
-#pragma unroll
-            for (int e = 0; e < 14; e++) {
-                const uint32_t v = (uint32_t)(y >> (4 * e)) & 15u;
-                const unsigned long long o = v == 15u ? 15ull : ((inc >> (4u * v)) & 15ull);
-                r |= o << (4 * e);
-            }
-            inc = r;
-        }
-    }
-    const unsigned long long exc = __shfl_up(inc, 1);
-    const uint32_t entry = lane == 0 ? 0u : (uint32_t)(exc & 15ull);
-    HPH(18);
-    /* count walk */
-    uint32_t cnt = 0, lastinfo = 0;
-    if (entry != 15u) {
-        uint32_t pos = ps + entry;
-        while (pos < ps + (uint32_t)HB) {
-            const uint32_t tk = hdr_token(sh, hdr_peek14(sh, pos));
-            if (!tk) break;
-            pos += tk & 255u;
-            cnt += (tk >> 8) & 255u;
-            const uint32_t kind = (tk >> 16) & 3u;
-            if (kind == 0u) lastinfo = 0x100u | (tk >> 24);
-            else if (kind == 2u) lastinfo = 0x100u;
-        }
-    }
-    uint32_t tot;
-    const uint32_t offs = wave_excl_sum(cnt, &tot);
-    /* length a leading "repeat previous" refers to */
-    uint32_t x = lastinfo;
-    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(x, dd); if (lane >= dd && !x) x = y; }
-    uint32_t prev = __shfl_up(x, 1);
-    if (lane == 0) prev = 0;
-    HPH(19);
-    /* write walk */
-    uint32_t endpos = 0xffffffffu, bad = 0;
-    if (entry != 15u && offs < total) {
-        uint32_t pos = ps + entry, idx = offs;
-        uint32_t pv = prev & 0xffu;
-        bool hp = (prev & 0x100u) != 0;
-        while (pos < ps + (uint32_t)HB && idx < total) {
-            const uint32_t tk = hdr_token(sh, hdr_peek14(sh, pos));
-            if (!tk) { bad = 1; break; }
-            pos += tk & 255u;
-            const uint32_t n = (tk >> 8) & 255u, kind = (tk >> 16) & 3u;
-            uint32_t val;
-            if (kind == 0u) { val = tk >> 24; pv = val; hp = true; }
-            else if (kind == 1u) { if (!hp) { bad = 1; break; } val = pv; }
-            else { val = 0; pv = 0; hp = true; }
-            if (idx + n > total) { bad = 1; break; }
-            for (uint32_t k = 0; k < n; k++) sh.lens[idx + k] = (uint8_t)val;
-            idx += n;
-            if (idx == total) endpos = pos;
-        }
-    } else if (entry == 15u && offs < total) bad = 1;
-    const unsigned long long anybad = __ballot(bad != 0);
-    const unsigned long long found = __ballot(endpos != 0xffffffffu);
-    if (anybad || !found || tot < total) {
-        if (lane == 0) sh.status = 2; /* the sequential decoder re-parses and reports real errors */
-    } else if (endpos != 0xffffffffu) {
-        sh.cur = cur + (endpos - lead);
-    }
-#undef HPH
-}
 
-/* The same resolution spread over the whole workgroup: 288 pieces of 16 bits (a code-length token is at
- * most 14 bits), one per thread, so the per-block header costs a few thousand cycles instead of one
- * wave's long dependent chain.  All PT threads call it (it contains barriers). */
+/* 288 pieces of 16 bits (a code-length token is at most 14 bits), one per thread, so the header costs a few
+ * thousand cycles instead of one long dependent chain.  All PT threads call it (it contains barriers). */
 constexpr int HB2 = 16;   /* header bits per thread */
 constexpr int HNP = 288;  /* pieces: 4608 bits >= any dynamic header */
 
@@ -879,7 +775,7 @@ __device__ __forceinline__ StreamView make_view(const uint8_t *rec, uint64_t rec
  * sh.status != 0 reports 1 = final block done, 2 = malformed / unsupported, 3 = needs the sequential
  * general-distance decoder.  All PT threads call it together. */
 template <int MODE>
-__device__ __forceinline__ void decode_one_block(ParShared &sh, uint8_t *stg, const StreamView &sv, int tid, unsigned long long *dbg,
+__device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView &sv, int tid, unsigned long long *dbg,
                                                  const ScratchOut &so /* MODE_SCRATCH only */,
                                                  HdrCache *hc /* NULL, or this block's decoded-header row */, uint32_t hctag)
 {
@@ -1155,29 +1051,6 @@ struct BlkJob {
     uint32_t pad;
 };
 
-/* RAW planes (zip.c:267-270): funnel-shifted dword copy from the (unaligned) payload */
-__global__ __launch_bounds__(PT) void k_raw_copy(const uint8_t *__restrict__ rec, const DecStream *__restrict__ ds,
-                                                 uint8_t *__restrict__ planes)
-{
-    const int tid = threadIdx.x;
-    const uint32_t s = blockIdx.x;
-    const DecStream d = ds[s];
-    if (!d.raw) return;
-    uint8_t *out = planes + (size_t)s * CHK;
-    const uint8_t *src = rec + d.payoff;
-    const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
-    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src - mis);
-    uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
-    uint32_t nw = d.n >> 2;
-    if (mis && nw) nw--; /* the funnel shift reads one dword ahead: keep it inside the payload */
-    const uint32_t shb = 8u * mis;
-    for (uint32_t i = blockIdx.y * PT + tid; i < nw; i += gridDim.y * PT) {
-        const uint32_t a = s32[i];
-        o32[i] = mis ? ((a >> shb) | (s32[i + 1] << (32u - shb))) : a;
-    }
-    if (blockIdx.y == 0)
-        for (uint32_t i = 4u * nw + tid; i < d.n; i += PT) out[i] = src[i];
-}
 
 /* D1: every bit position of every compressed payload is tested for the signature of a dynamic-block
  * header as zlib writes it in Z_RLE streams: BFINAL=0, BTYPE=2, HLIT <= 29, HDIST == 1, and a complete
@@ -1490,7 +1363,6 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
      * where it ends and how much it produced; k_chain then keeps the candidates that form the stream's chain */
     HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
     ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
-    uint8_t *stg = reinterpret_cast<uint8_t *>(dynsm) + ((sizeof(ParShared) + 15u) & ~(size_t)15u);
     const int tid = threadIdx.x;
     const uint32_t job = blockIdx.x;
     uint32_t lo = 0, hi = nstreams - 1;
@@ -1507,7 +1379,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     __syncthreads();
     ScratchOut so;
     so.base = scratch; so.top = scratch_top; so.cap16 = scratch_cap16; so.wbase = c->wbase; so.wlen = c->wlen;
-    decode_one_block<MODE_SCRATCH>(sh, stg, sv, tid, dbg, so, hdrs + ((size_t)s * MAXCAND + ci), hdr_tag(calltag, c->bit));
+    decode_one_block<MODE_SCRATCH>(sh, sv, tid, dbg, so, hdrs + ((size_t)s * MAXCAND + ci), hdr_tag(calltag, c->bit));
     __syncthreads();
     if (tid == 0) {
         const bool ok = (sh.status == 0 || sh.status == 1) && sh.cur > c->bit;
@@ -1651,11 +1523,10 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
 {
     HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
     ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
-    uint8_t *stg = reinterpret_cast<uint8_t *>(dynsm) + ((sizeof(ParShared) + 15u) & ~(size_t)15u);
     const int tid = threadIdx.x;
     const uint32_t s = blockIdx.x;
     const DecStream d = ds[s];
-    if (d.raw) return;                  /* k_raw_copy */
+    if (d.raw) return;                  /* RAW planes are read straight from the payload by k_merge_planes */
     if (only && only[s] == 0) return;   /* already decoded block-parallel */
     const StreamView sv = make_view(rec, reclen, d, planes + (size_t)s * CHK);
     if (tid == 0) { sh.cur = 0; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
@@ -1665,7 +1536,7 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
         if (sh.status != 0) break;
         if (sh.op >= sv.n) { if (tid == 0) sh.status = 1; __syncthreads(); break; }
         if (dbg && tid == 0) sh.acc[10]++;
-        decode_one_block<MODE_FINAL>(sh, stg, sv, tid, dbg, ScratchOut(), nullptr, 0u);
+        decode_one_block<MODE_FINAL>(sh, sv, tid, dbg, ScratchOut(), nullptr, 0u);
         __syncthreads();
     }
     __syncthreads();
