@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _product_built():
+    """The built libraries are git-ignored: in a fresh checkout compile them once (hipcc cross-compiles gfx950
+    without a GPU).  Importing the package without its HIP library fails on purpose (there is no CPU fallback)."""
+    lib = os.path.join(ROOT, "datacompressionfloat_amd", "lib", "libmrcz_hip.so")
+    workers = os.path.join(ROOT, "datacompressionfloat_amd", "lib", "libmrcz_workers.so")
+    if not (os.path.exists(lib) and os.path.exists(workers)):
+        import __graft_entry__ as g
+        g.build()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """CPU oracle (oracle/liboracle.so); built on demand with gcc."""
