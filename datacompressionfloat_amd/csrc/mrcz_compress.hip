@@ -790,6 +790,23 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
         __builtin_amdgcn_wave_barrier(); /* the previous tile's readers are done */
         uint32_t x[16];
         load_plane_row(pl, t0, len, lane, x);
+        if (si.raw) {
+            /* RAW plane (zip.c:184-190): the payload is the plane itself.  Each lane stores its own 64 bytes with four
+             * 16-byte stores at whatever alignment the payload has (gfx9 global memory takes unaligned accesses);
+             * nothing is shared between lanes, so no LDS and no atomics (wave-uniform branch). */
+            uint8_t *dst = out + si.payoff + t0 + 64u * (uint32_t)lane;
+            const int mine = len - 64 * lane; /* bytes of this lane's row inside the chunk */
+            if (mine >= 64) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint4 v = make_uint4(x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]);
+                    __builtin_memcpy(dst + 16 * k, &v, 16);
+                }
+            } else {
+                for (int i = 0; i < mine; i++) dst[i] = (uint8_t)(x[i >> 2] >> (8 * (i & 3)));
+            }
+            continue;
+        }
         {
             /* the tile also goes to LDS: the verbatim path reads it byte-wise across lanes, the coded path re-reads
              * its own row in quarters to keep the packer's register footprint small */
