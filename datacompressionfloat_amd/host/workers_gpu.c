@@ -17,7 +17,7 @@
 int isTestThroughput = 0; /* src/core/workers.c:39 */
 
 static __thread int t_device = 0;
-static __thread int t_batch_chunks = 16;
+static __thread int t_batch_chunks = 8; /* 192 MiB of floats per batch: pinning host memory costs ~0.2 s per GiB */
 
 void mrcz_workers_set_device(int device) { t_device = device; }
 void mrcz_workers_set_batch_chunks(int chunks) { t_batch_chunks = chunks < 1 ? 1 : (chunks > 128 ? 128 : chunks); }
@@ -26,6 +26,55 @@ static void die(const char *what, mrcz_ctx_t *c)
 {
     fprintf(stderr, "[%s:%d] ERROR: %s: %s\n", __FILE__, __LINE__, what, c ? mrcz_last_error(c) : "");
     exit(-1);
+}
+
+/* ---- per-thread session: codec context + pinned / device staging buffers, kept between calls ----
+ * The reference's worker threads call run_compress / run_uncompress once per file (adapt.c:28-90).  Creating a
+ * context and pinning a gigabyte of host memory costs far more than coding a file, so a thread keeps its session
+ * until it exits (or its device / batch size changes). */
+typedef struct {
+    mrcz_ctx_t *c;
+    int device, batch;
+    void *h_fl[2]; /* pinned: up to batch floats each (the second one only once a file needs a second batch) */
+    void *h_rec;   /* pinned: records of a batch */
+    void *d_fl;    /* device: batch floats */
+    void *d_rec;   /* device: records of a batch */
+    uint64_t h_fl_cap[2], h_rec_cap, d_fl_cap, d_rec_cap; /* bytes; buffers grow to what the files so far needed */
+} session_t;
+static __thread session_t t_s;
+static pthread_key_t s_key;
+static pthread_once_t s_once = PTHREAD_ONCE_INIT;
+
+static void session_release(void *p)
+{
+    session_t *s = (session_t *)p;
+    if (!s || !s->c) return;
+    mrcz_host_free(s->c, s->h_fl[0]); mrcz_host_free(s->c, s->h_fl[1]); mrcz_host_free(s->c, s->h_rec);
+    mrcz_dev_free(s->c, s->d_fl); mrcz_dev_free(s->c, s->d_rec);
+    mrcz_destroy(s->c);
+    memset(s, 0, sizeof(*s));
+}
+static void session_key_init(void) { pthread_key_create(&s_key, session_release); }
+
+static session_t *session_get(void)
+{
+    pthread_once(&s_once, session_key_init);
+    if (t_s.c && (t_s.device != t_device || t_s.batch != t_batch_chunks)) session_release(&t_s);
+    if (!t_s.c) {
+        if (mrcz_create(&t_s.c, t_device, (uint32_t)t_batch_chunks) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
+        t_s.device = t_device;
+        t_s.batch = t_batch_chunks;
+        pthread_setspecific(s_key, &t_s); /* released when the thread exits */
+    }
+    return &t_s;
+}
+/* make a staging buffer at least `need` bytes large (never shrinks) */
+static void session_grow(session_t *s, void **p, uint64_t *cap, uint64_t need, int host)
+{
+    if (*cap >= need && *p) return;
+    if (*p) { if (host) mrcz_host_free(s->c, *p); else mrcz_dev_free(s->c, *p); *p = NULL; *cap = 0; }
+    if ((host ? mrcz_host_malloc(s->c, p, need) : mrcz_dev_malloc(s->c, p, need)) != MRCZ_OK) die("fail to alloc mem", s->c);
+    *cap = need;
 }
 
 /* ---- double-buffered reader: fread of batch k+1 overlaps the GPU work on batch k ---- */
@@ -54,14 +103,19 @@ int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const 
         exit(-1);
     }
     double begin = now_sec();
-    mrcz_ctx_t *c = NULL;
-    if (mrcz_create(&c, t_device, (uint32_t)t_batch_chunks) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
-    const uint64_t batch_floats = (uint64_t)t_batch_chunks * CHUNK_SIZE;
-    const uint64_t rec_cap = mrcz_records_bound(batch_floats);
-    void *h_in[2] = {NULL, NULL}, *h_out = NULL, *d_in = NULL, *d_out = NULL;
-    if (mrcz_host_malloc(c, &h_in[0], batch_floats * 4) || mrcz_host_malloc(c, &h_in[1], batch_floats * 4) ||
-        mrcz_host_malloc(c, &h_out, rec_cap) || mrcz_dev_malloc(c, &d_in, batch_floats * 4) || mrcz_dev_malloc(c, &d_out, rec_cap))
-        die("fail to alloc mem", c);
+    session_t *ses = session_get();
+    mrcz_ctx_t *c = ses->c;
+    const uint64_t batch_floats = (uint64_t)ses->batch * CHUNK_SIZE;
+    /* staging sized by what this file needs: a small file does not pin a whole batch */
+    const uint64_t file_floats = (uint64_t)get_file_size(fin) / 4u;
+    const uint64_t stage_floats = file_floats < batch_floats ? (file_floats ? file_floats : 1) : batch_floats;
+    const uint64_t rec_cap = mrcz_records_bound(stage_floats) + 64;
+    session_grow(ses, &ses->h_fl[0], &ses->h_fl_cap[0], stage_floats * 4, 1);
+    if (file_floats >= batch_floats) session_grow(ses, &ses->h_fl[1], &ses->h_fl_cap[1], batch_floats * 4, 1); /* a next batch will be read */
+    session_grow(ses, &ses->h_rec, &ses->h_rec_cap, rec_cap, 1);
+    session_grow(ses, &ses->d_fl, &ses->d_fl_cap, stage_floats * 4, 0);
+    session_grow(ses, &ses->d_rec, &ses->d_rec_cap, rec_cap, 0);
+    void *h_in[2] = {ses->h_fl[0], ses->h_fl[1]}, *h_out = ses->h_rec, *d_in = ses->d_fl, *d_out = ses->d_rec;
 
     mrczip_header_t hd;
     init_mrczip_header(&hd, 0);
@@ -101,9 +155,6 @@ int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const 
     }
     /* workers.c:870-873: sum of the per-plane compressed sizes (each includes its 4-byte header) */
     for (int j = 0; j < 4; j++) ctx->allZipFileSize += plane_total[j];
-    mrcz_host_free(c, h_in[0]); mrcz_host_free(c, h_in[1]); mrcz_host_free(c, h_out);
-    mrcz_dev_free(c, d_in); mrcz_dev_free(c, d_out);
-    mrcz_destroy(c);
     return 0;
 }
 
@@ -127,14 +178,16 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
     double start = now_sec();
     const uint64_t nfloats = hd->fsz / COMPRESSION_PATH_NUM; /* workers.c:577 */
     const uint32_t chk = hd->chk;
-    mrcz_ctx_t *c = NULL;
-    if (mrcz_create(&c, t_device, (uint32_t)t_batch_chunks) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
-    const uint64_t batch_floats = (uint64_t)t_batch_chunks * chk;
-    const uint64_t rec_cap = mrcz_records_bound((uint64_t)t_batch_chunks * CHUNK_SIZE) + 64;
-    void *h_rec = NULL, *h_out = NULL, *d_rec = NULL, *d_out = NULL;
-    if (mrcz_host_malloc(c, &h_rec, rec_cap) || mrcz_host_malloc(c, &h_out, batch_floats * 4) ||
-        mrcz_dev_malloc(c, &d_rec, rec_cap) || mrcz_dev_malloc(c, &d_out, batch_floats * 4))
-        die("fail to alloc mem", c);
+    session_t *ses = session_get();
+    mrcz_ctx_t *c = ses->c;
+    const uint64_t batch_floats = (uint64_t)ses->batch * chk;
+    const uint64_t stage_floats = nfloats < batch_floats ? (nfloats ? nfloats : 1) : batch_floats;
+    const uint64_t rec_cap = mrcz_records_bound((stage_floats + chk - 1) / chk * CHUNK_SIZE) + 64;
+    session_grow(ses, &ses->h_rec, &ses->h_rec_cap, rec_cap, 1);
+    session_grow(ses, &ses->h_fl[0], &ses->h_fl_cap[0], stage_floats * 4, 1);
+    session_grow(ses, &ses->d_rec, &ses->d_rec_cap, rec_cap, 0);
+    session_grow(ses, &ses->d_fl, &ses->d_fl_cap, stage_floats * 4, 0);
+    void *h_rec = ses->h_rec, *h_out = ses->h_fl[0], *d_rec = ses->d_rec, *d_out = ses->d_fl;
     ctx->unzipTime += now_sec() - start;
 
     uint64_t done = 0, zbytes = 0;
@@ -167,7 +220,5 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
     /* workers.c:679-685: decoded bytes and compressed bytes (plane payloads; chunk headers are not counted there) */
     ctx->allFileSize += nfloats * 4;
     ctx->allZipFileSize += zbytes - 16 * ((nfloats + chk - 1) / chk);
-    mrcz_host_free(c, h_rec); mrcz_host_free(c, h_out); mrcz_dev_free(c, d_rec); mrcz_dev_free(c, d_out);
-    mrcz_destroy(c);
     return 0;
 }

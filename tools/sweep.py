@@ -53,16 +53,17 @@ def measure(codec, words, bits):
 
 res = {"device": torch.cuda.get_device_name(0), "note": "HBM-resident, 3 repetitions after one warm-up, bit-exact round trip asserted"}
 n = 268435456
-codec = MrcZipCodec(0, max_batch_chunks=43)
-w = volume(n)
-res["config2_1GiB_mask_sweep"] = [measure(codec, w, b) for b in (0, 8, 12, 16, 23)]
-del w
-# config 3: mrc_small shape -- 1024-byte header + 1024 x 1024 x 16 Poisson-like detector counts as float32
-g = torch.Generator(device=dev).manual_seed(7)
-cnt = torch.poisson(torch.full((16 * 1048576,), 8.0, device=dev), generator=g)
-w3 = torch.cat([torch.zeros(256, dtype=torch.float32, device=dev), cnt]).view(torch.int32).contiguous()
-res["config3_mrc_small_64MiB_poisson"] = [measure(codec, w3, b) for b in (0, 8)]
-codec.close()
+if "--cli-only" not in sys.argv:
+    codec = MrcZipCodec(0, max_batch_chunks=43)
+    w = volume(n)
+    res["config2_1GiB_mask_sweep"] = [measure(codec, w, b) for b in (0, 8, 12, 16, 23)]
+    del w
+    # config 3: mrc_small shape -- 1024-byte header + 1024 x 1024 x 16 Poisson-like detector counts as float32
+    g = torch.Generator(device=dev).manual_seed(7)
+    cnt = torch.poisson(torch.full((16 * 1048576,), 8.0, device=dev), generator=g)
+    w3 = torch.cat([torch.zeros(256, dtype=torch.float32, device=dev), cnt]).view(torch.int32).contiguous()
+    res["config3_mrc_small_64MiB_poisson"] = [measure(codec, w3, b) for b in (0, 8)]
+    codec.close()
 
 # command-line tools end to end on a 1 GiB file in /dev/shm (what a user of mrc_tar sees: file I/O + PCIe + codec)
 shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
@@ -78,6 +79,33 @@ with tempfile.TemporaryDirectory(dir=shm) as d:
         dt = time.perf_counter() - t0
         e2e[name] = {"wall_s": round(dt, 3), "GBps_of_floats": round(4.0 * n / dt / 1e9, 2)}
     res["cli_end_to_end_1GiB_devshm"] = e2e
+    # config 5 shape, scaled to one GPU: a list of 8 files x 256 MiB through mrc_tarx (worker threads keep their codec
+    # session between files), zip then unzip, wall time of the whole command
+    tarx = os.path.join(ROOT, "datacompressionfloat_amd", "bin", "mrc_tarx")
+    files = []
+    for i in range(8):
+        f = os.path.join(d, f"part{i}.mrc")
+        volume(n // 4, seed=100 + i).cpu().numpy().tofile(f)
+        files.append(f)
+    lst, zl = os.path.join(d, "files.txt"), os.path.join(d, "zips.txt")
+    zdir, udir = os.path.join(d, "z"), os.path.join(d, "u")
+    os.mkdir(zdir); os.mkdir(udir)
+    open(lst, "w").write("\n".join(files) + "\n")
+    multi = {}
+    for nthreads in (1, 2, 4):
+        t0 = time.perf_counter()
+        subprocess.run([tarx, "-i", lst, "-t", "zip", "-o", zdir, "-b", "8", "-n", str(nthreads)], stdout=subprocess.DEVNULL, check=True)
+        t1 = time.perf_counter()
+        zips = sorted(os.path.join(zdir, x) for x in os.listdir(zdir))
+        open(zl, "w").write("\n".join(zips) + "\n")
+        subprocess.run([tarx, "-i", zl, "-t", "unzip", "-o", udir, "-n", str(nthreads)], stdout=subprocess.DEVNULL, check=True)
+        t2 = time.perf_counter()
+        multi[f"threads_{nthreads}"] = {"zip_GBps": round(8 * n / (t1 - t0) / 1e9, 2), "unzip_GBps": round(8 * n / (t2 - t1) / 1e9, 2)}
+        for x in zips:
+            os.remove(x)
+        for x in os.listdir(udir):
+            os.remove(os.path.join(udir, x))
+    res["cli_mrc_tarx_8x256MiB_devshm"] = multi
     # the reference itself, one thread, 64 MiB block (config 1): compress + decompress wall time
     ref = os.path.join(ROOT, "oracle", "_ref", "mrc_tar_c")
     if os.path.exists(ref):
