@@ -206,7 +206,7 @@ def main():
                     "avg_launch_ms": round(acc[dom], 4),
                     "kernel_ms": {k: round(v, 4) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
             cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
             sample = words[: 16 * 1048576].cpu().numpy()  # first 64 MiB of the volume (3 chunks)
             cpu = cpu_baseline(sample, args.bits, cores)
