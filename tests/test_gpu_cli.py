@@ -92,3 +92,23 @@ def test_cross_decode_with_the_reference_binary(tmp_path):
     assert _run([ref, "-i", str(z1), "-o", str(b1), "-t", "unzip"]).returncode == 0      # reference decodes GPU output
     assert _run([exe, "-i", str(z2), "-o", str(b2), "-t", "unzip"]).returncode == 0      # GPU decodes reference output
     assert b1.read_bytes() == b2.read_bytes() == util.erase_expected(w, 10).tobytes()
+
+
+def test_erasebytes_tool_matches_the_reference_tool(tmp_path):
+    """the verification tool with the reference's command line, masking on the GPU; compared with the
+    reference's own erasebytes (built as oracle/_ref/erasebytes_c) where present, and with numpy always."""
+    exe = os.path.join(BIN, "erasebytes")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    ref = os.path.join(util.ROOT, "oracle", "_ref", "erasebytes_c")
+    for n, bits, tail in ((100, 8, b""), (256, 8, b""), (70001, 12, b"xy"), (2 * util.CHUNK + 3, 23, b"")):
+        w = util.gauss_words(n, seed=n & 511)
+        src, dst = tmp_path / "in.mrc", tmp_path / "out.mrc"
+        src.write_bytes(w.tobytes() + tail)
+        r = _run([exe, "-i", str(src), "-o", str(dst), "-b", str(bits)])
+        assert r.returncode == 0, r.stderr
+        got = dst.read_bytes()
+        assert got == util.erase_expected(w, bits).tobytes()
+        if os.path.exists(ref) and 4 * n >= 1024:  # below 1024 bytes the reference writes 1024 bytes of its malloc'd buffer
+            rdst = tmp_path / "ref.mrc"
+            r = _run([ref, "-i", str(src), "-o", str(rdst), "-b", str(bits)])
+            assert r.returncode == 0 and rdst.read_bytes() == got
