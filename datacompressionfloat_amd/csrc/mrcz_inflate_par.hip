@@ -1,33 +1,42 @@
 /*
- * mrcz_inflate_par.hip -- workgroup-cooperative raw inflate: one 1024-thread workgroup per
- * (chunk, plane) stream (replaces mzlib_inf, /root/reference/src/core/zip.c:262-284, one zlib
- * inflate() per plane per chunk).
+ * mrcz_inflate_par.hip -- block-parallel raw inflate of the plane streams (replaces mzlib_inf,
+ * /root/reference/src/core/zip.c:262-284: one zlib inflate() per plane per chunk).
  *
- * The container carries no intra-stream index, so a stream is a sequential chain of deflate blocks;
- * inside a block the symbols are decoded in parallel.  Prefix codes of near-uniform byte planes are
- * almost fixed-length and do NOT self-synchronise, so instead of iterating guesses the kernel
- * resolves the parse exactly:
- *   P1  the compressed bits are staged into LDS in windows of 1024 x 256 bits; every lane owns one
- *       256-bit piece and, walking its bit positions backwards, computes the piece's EXIT FUNCTION:
- *       for a token starting e bits into the piece (e < 24), how many bits into the next piece the
- *       token chain lands (24 x 5-bit entries packed in two 64-bit registers; 31 = chain hit
- *       END_BLOCK, 30 = invalid / unsupported token);
- *   P2  exit functions are composed with a Kogge-Stone scan over the wave (shuffles) and a fold over
- *       the 16 wave totals, giving every lane the true entry offset of its piece;
- *   P3  lanes walk their piece from the true entry counting plane bytes; a workgroup scan yields
- *       output offsets and the byte a distance-1 match replicates;
- *   P4  lanes walk once more and write plane bytes.
- * Streams written by this codec (and by zlib Z_RLE) only contain distance-1 matches and tokens of at
- * most 15+5+1 bits; a stream with other distances or tokens longer than 24 bits is handed to the
- * sequential decoder in mrcz_inflate.hip.
+ * The container carries no intra-stream index and a deflate block's start is only known once the block before it has
+ * been decoded, so a stream is a sequential chain of ~190 blocks.  The kernels here break that chain speculatively:
+ *   k_scan_candidates      every bit position of every payload is tested for the fixed fields of a dynamic block
+ *                          header as Z_RLE streams carry them, survivors for a complete code-length code;
+ *   k_validate_candidates  one lane per survivor parses the whole header; the decoded code lengths are kept;
+ *   k_blk_count            one 512-thread workgroup per candidate decodes the block as if it were real, leaves its
+ *                          bytes in a scratch buffer and records where it ends and what it produced;
+ *   k_chain                per stream, keeps the candidates that start exactly where the previous block ended
+ *                          (stored blocks are sized on the spot) and assigns plane offsets;
+ *   k_blk_gather           moves the accepted blocks from scratch to their place in the plane;
+ *   k_inflate_par          fallback: walks a stream's blocks one after the other with the same per-block code
+ *                          (streams whose chain did not close: static blocks, foreign encoders, ...).
+ * Correctness never depends on the speculation: a block is only used if the chain from bit 0 reaches it.
+ *
+ * Inside a block (decode_one_block) the symbols are decoded in parallel.  Prefix codes of near-uniform byte planes
+ * are almost fixed-length and do NOT self-synchronise, so the parse is resolved exactly, window by window
+ * (512 x 256 bits staged in LDS, one 256-bit piece per lane):
+ *   P1  every lane runs the backward recurrence exit[k] = exit[k + bits(token at k)] over all bit positions of its
+ *       piece (exit values in a lane-private LDS ring): for a token starting e bits into the piece (e < 24), how many
+ *       bits into the next piece the token chain lands (31 = chain hit END_BLOCK, 30 = invalid / unsupported token);
+ *   P2  the pieces' entry offsets follow by chained table walks inside each wave and a fold over the wave totals;
+ *   P3  lanes walk their piece from the true entry counting plane bytes; workgroup scans yield output offsets and
+ *       the byte a distance-1 match replicates;
+ *   P4  lanes walk once more and write plane bytes (packed dword stores, wide stores for long runs).
+ * Streams written by this codec (and by zlib Z_RLE) only contain distance-1 matches and tokens of at most 15+5+1
+ * bits; a stream with other distances or tokens longer than 24 bits is handed to the sequential decoder in
+ * mrcz_inflate.hip.
  */
 #include "mrcz_common.h"
 
 namespace mrcz {
 
-constexpr int PT = 512;                       /* threads per workgroup (2 workgroups per CU: 128 VGPRs each) */
+constexpr int PT = 512;                       /* threads per workgroup (3 workgroups per CU: <= 80 VGPRs, <= 42 LDS granules each) */
 constexpr int SUBBITS = 256;                  /* bits per lane piece */
-constexpr int WINBITS = PT * SUBBITS;         /* 32 KiB of compressed data per window */
+constexpr int WINBITS = PT * SUBBITS;         /* 16 KiB of compressed data per window */
 constexpr int MAXTOK = 24;                    /* longest token (bits) the parallel path resolves */
 constexpr uint32_t X_ERR = 30u, X_EOB = 31u;
 constexpr int WIN_WORDS = WINBITS / 32 + 8;   /* + alignment lead + lookahead */
