@@ -5,12 +5,12 @@
  * src/core/zip.c:262-284: one raw inflate per plane per chunk, or RAW passthrough) and
  * merge_byte_to_float_stream (workers.c:423-442).  Every (chunk, plane) payload is an independent
  * raw-deflate stream (each ends on a Z_FULL_FLUSH boundary and its first symbol is a literal), so
- * streams are decoded concurrently, one wave per stream.
+ * streams are decoded concurrently.
  *
  *   k_parse_records  walks the 16-byte chunk headers (unpack_header, zip.c:393-399)
- *   k_inflate_par    (mrcz_inflate_par.hip) 1024 threads per stream, self-synchronising parallel decode
- *   k_inflate        sequential general decoder (any distance); only runs for streams the parallel
- *                    kernel hands over (matches with distance != 1, or malformed input)
+ *   (mrcz_inflate_par.hip)  the block-parallel decoder proper: candidate scan, speculative block decode, chain, gather
+ *   k_inflate        sequential general decoder (any distance), one wave per stream; only runs for streams the
+ *                    parallel kernels hand over (matches with distance != 1, or malformed input)
  *   k_merge_planes   4 byte planes -> float words (uint4 stores)
  */
 #include "mrcz_common.h"

@@ -1,9 +1,8 @@
 /*
- * mrcz_tile.h -- tile staging shared by the three streaming passes of the compressor
- * (k_tile_summary, k_histogram, k_emit): coalesced float4 loads of a 4096-float tile, bit mask
- * (apply_mask, /root/reference/src/core/workers.c:82-101), 4x4 byte transpose into four LDS plane
- * tiles (split_float_to_byte_stream, workers.c:180-203), then each wave takes one plane with 64
- * consecutive positions per lane and derives the run-start bitmask.
+ * mrcz_tile.h -- tile helpers of the compressor.  k_tile_summary stages a 4096-float tile: coalesced float4 loads,
+ * bit mask (apply_mask, /root/reference/src/core/workers.c:82-101), 4x4 byte transpose into four LDS plane tiles
+ * (split_float_to_byte_stream, workers.c:180-203), and leaves the planes in HBM; every pass then gives a wave one
+ * plane tile with 64 consecutive positions per lane and derives the run-start bitmask from the lane's row.
  */
 #pragma once
 #include "mrcz_common.h"
