@@ -21,11 +21,17 @@
 using namespace mrcz;
 
 #define MAX_TIMERS 32
+#define MAX_LANES 4
 
 struct mrcz_ctx {
     int device;
     uint32_t max_chunks;
-    hipStream_t stream;
+    hipStream_t stream;            /* everything except ...                                                     */
+    hipStream_t lane_stream[MAX_LANES]; /* ... the lanes of a compress batch (see mrcz_compress_chunks); [0] = stream */
+    hipEvent_t ev_start, ev_cont, ev_done[MAX_LANES];
+    uint32_t lanes;                /* lanes per compress batch: 2 measured best (1: 292, 2: 306, 3: 307, 4: 229 GB/s -- with four
+                                    * Huffman kernels resident their 72 KB workgroups starve the streaming kernels of LDS);
+                                    * MRCZ_LANES overrides it for experiments */
     char err[256];
     /* workspace (sized for max_chunks chunks = 4*max_chunks streams) */
     TileSum *tsum;
@@ -108,6 +114,13 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     const size_t ns = 4u * (size_t)max_batch_chunks;
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
+    ctx->lane_stream[0] = ctx->stream;
+    ctx->lanes = 2;
+    if (const char *ev = getenv("MRCZ_LANES")) { const int v = atoi(ev); if (v >= 1 && v <= MAX_LANES) ctx->lanes = (uint32_t)v; }
+    for (int l = 1; l < MAX_LANES && e == hipSuccess; l++) e = hipStreamCreate(&ctx->lane_stream[l]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_cont, hipEventDisableTiming);
+    for (int l = 1; l < MAX_LANES && e == hipSuccess; l++) e = hipEventCreateWithFlags(&ctx->ev_done[l], hipEventDisableTiming);
     if (e == hipSuccess) e = dalloc(&ctx->tsum, ns * TPS);
     if (e == hipSuccess) e = dalloc(&ctx->tinfo, ns * TPS);
     if (e == hipSuccess) e = dalloc(&ctx->sinfo, ns);
@@ -121,8 +134,8 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->lay, ns * MAXBLK);
     if (e == hipSuccess) e = dalloc(&ctx->pairbits, ns * MAXPAIR);
     if (e == hipSuccess) e = dalloc(&ctx->pairoff, ns * MAXPAIR);
-    if (e == hipSuccess) e = dalloc(&ctx->blkbase, ns + 1);
-    if (e == hipSuccess) e = dalloc(&ctx->result, 8);
+    if (e == hipSuccess) e = dalloc(&ctx->blkbase, ns + MAX_LANES); /* one prefix array per lane */
+    if (e == hipSuccess) e = dalloc(&ctx->result, 16);
     if (e == hipSuccess) e = dalloc(&ctx->dstreams, ns);
     if (e == hipSuccess) e = dalloc(&ctx->fallback, ns);
     if (e == hipSuccess) e = dalloc(&ctx->cands, ns * MAXCAND);
@@ -165,6 +178,12 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_cont) (void)hipEventDestroy(ctx->ev_cont);
+    for (int l = 1; l < MAX_LANES; l++) {
+        if (ctx->ev_done[l]) (void)hipEventDestroy(ctx->ev_done[l]);
+        if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -185,12 +204,13 @@ extern "C" uint64_t mrcz_records_bound(uint64_t nfloats)
 }
 
 /* run one kernel launch, optionally timed with HIP events on the context's stream */
+/* `lstream` = the HIP stream the enclosing function launches on (a local variable) */
 #define LAUNCH(name, kernel, grid, block, ...)                                              \
     do {                                                                                    \
-        if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);                       \
-        hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, __VA_ARGS__);               \
+        if (ctx->timing) (void)hipEventRecord(ctx->ev0, lstream);                       \
+        hipLaunchKernelGGL(kernel, grid, block, 0, lstream, __VA_ARGS__);               \
         if (ctx->timing) {                                                                  \
-            (void)hipEventRecord(ctx->ev1, ctx->stream);                                    \
+            (void)hipEventRecord(ctx->ev1, lstream);                                    \
             (void)hipEventSynchronize(ctx->ev1);                                            \
             float ms_ = 0.f;                                                                \
             (void)hipEventElapsedTime(&ms_, ctx->ev0, ctx->ev1);                            \
@@ -202,10 +222,10 @@ extern "C" uint64_t mrcz_records_bound(uint64_t nfloats)
 /* same, with dynamic LDS */
 #define LAUNCH_S(name, kernel, grid, block, shmem, ...)                                     \
     do {                                                                                    \
-        if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);                       \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, __VA_ARGS__);           \
+        if (ctx->timing) (void)hipEventRecord(ctx->ev0, lstream);                       \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, lstream, __VA_ARGS__);           \
         if (ctx->timing) {                                                                  \
-            (void)hipEventRecord(ctx->ev1, ctx->stream);                                    \
+            (void)hipEventRecord(ctx->ev1, lstream);                                    \
             (void)hipEventSynchronize(ctx->ev1);                                            \
             float ms_ = 0.f;                                                                \
             (void)hipEventElapsedTime(&ms_, ctx->ev0, ctx->ev1);                            \
@@ -244,6 +264,50 @@ static int ensure_planes(mrcz_ctx *ctx)
     return MRCZ_OK;
 }
 
+/* One half ("lane") of a compress batch: chunks [c_first, c_first + nb) of the batch, whose workspace rows start at
+ * stream s0 = 4 * (chunks of the batch before this lane).  phase 0 = everything up to the sizes (summary ... pair
+ * offsets), phase 1 = layout in the output, phase 2 = zero + headers + emit.  The kernels index the workspace by the
+ * lane-local stream number, so a lane is just a set of offset base pointers. */
+static int compress_lane(mrcz_ctx *ctx, hipStream_t lstream, int phase, int slot, uint32_t s0, const uint32_t *bin, uint64_t bfl,
+                         uint32_t nb, uint32_t mask, uint32_t fstart, uint8_t *out)
+{
+    const uint32_t ns = 4u * nb;
+    TileSum *tsum = ctx->tsum + (size_t)s0 * TPS;
+    TileInfo *tinfo = ctx->tinfo + (size_t)s0 * TPS;
+    StreamInfo *sinfo = ctx->sinfo + s0;
+    uint32_t *blkstart = ctx->blkstart + (size_t)s0 * (MAXBLK + 1);
+    uint32_t *slideq = ctx->slideq + (size_t)s0 * MAXSLIDE;
+    uint16_t *pairhist = ctx->pairhist + (size_t)s0 * MAXPAIR * HROW;
+    uint16_t *blkfreq = ctx->blkfreq + (size_t)s0 * MAXBLK * HROW;
+    uint32_t *blkcode = ctx->blkcode + (size_t)s0 * MAXBLK * HROW;
+    uint32_t *blkhdr = ctx->blkhdr + (size_t)s0 * MAXBLK * HDRWORDS;
+    BlkMeta *meta = ctx->meta + (size_t)s0 * MAXBLK;
+    BlkLay *lay = ctx->lay + (size_t)s0 * MAXBLK;
+    uint32_t *pairbits = ctx->pairbits + (size_t)s0 * MAXPAIR;
+    uint32_t *pairoff = ctx->pairoff + (size_t)s0 * MAXPAIR;
+    uint32_t *blkbase = ctx->blkbase + s0 + (uint32_t)slot; /* lane l needs 4 nb_l + 1 entries */
+    uint8_t *planes = ctx->planes + (size_t)s0 * CHK;
+    if (phase == 0) {
+        LAUNCH("k_tile_summary", k_tile_summary, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, tsum, planes);
+        LAUNCH("k_stream_scan", k_stream_scan, dim3(ns), dim3(256), tsum, bfl, tinfo, sinfo, blkstart);
+        LAUNCH("k_histogram", k_histogram, dim3(SPS, nb, 4), dim3(64), planes, bfl, tinfo, pairhist, blkstart, slideq);
+        LAUNCH("k_block_reduce", k_block_reduce, dim3(MAXBLK, ns), dim3(64), tinfo, sinfo, pairhist, blkfreq);
+        LAUNCH("k_block_index", k_block_index, dim3(1), dim3(256), sinfo, ns, blkbase);
+        LAUNCH("k_huffman", k_huffman, dim3((ns * MAXBLK + HT - 1) / HT), dim3(HT), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta);
+        LAUNCH("k_stream_layout", k_stream_layout, dim3(ns), dim3(64), sinfo, meta, blkstart, slideq, lay);
+        LAUNCH("k_pair_bits", k_pair_bits, dim3(SPS, ns), dim3(64), sinfo, lay, pairhist, blkcode, tinfo, pairbits);
+        LAUNCH("k_pair_offsets", k_pair_offsets, dim3(ns), dim3(64), sinfo, lay, tinfo, pairbits, pairoff);
+    } else if (phase == 1) {
+        LAUNCH("k_container", k_container, dim3(1), dim3(256), sinfo, nb, out, ctx->result, 0, slot);
+    } else {
+        LAUNCH("k_zero_records", k_zero_records, dim3(2048), dim3(256), out, ctx->result, slot);
+        LAUNCH("k_container", k_container, dim3(1), dim3(256), sinfo, nb, out, ctx->result, 1, slot);
+        LAUNCH("k_emit", k_emit, dim3(SPS, nb, 4), dim3(64), planes, bfl, tinfo, sinfo, lay, blkstart, blkcode, pairoff, out);
+        LAUNCH("k_emit_headers", k_emit_headers, dim3(MAXBLK + 1, ns), dim3(64), sinfo, lay, meta, blkhdr, blkstart, out);
+    }
+    return MRCZ_OK;
+}
+
 extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk, int bits,
                                     void *d_out, uint64_t out_cap, uint64_t *out_len, uint64_t plane_bytes[4])
 {
@@ -261,34 +325,44 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
     const uint32_t *in = (const uint32_t *)d_in;
     uint8_t *out = (uint8_t *)d_out;
     if (int rc = ensure_planes(ctx)) return rc;
-    HIPCHK(hipMemsetAsync(ctx->result, 0, 8 * sizeof(uint64_t), ctx->stream), "memset result");
-
+    HIPCHK(hipMemsetAsync(ctx->result, 0, 16 * sizeof(uint64_t), ctx->stream), "memset result");
+    HIPCHK(hipEventRecord(ctx->ev_start, ctx->stream), "event");
+    for (int l = 1; l < MAX_LANES; l++) HIPCHK(hipStreamWaitEvent(ctx->lane_stream[l], ctx->ev_start, 0), "wait");
+    /* A batch runs as ctx->lanes lanes (contiguous parts of its chunks), one stream each: the Huffman kernel is
+     * one tree's latency long (0.9 ms whatever the number of trees) and leaves most of the machine idle, so the other
+     * lanes' streaming passes and emit kernels run under it, and the lanes' Huffman kernels under each other.  Only
+     * the layout step is ordered across lanes (running byte offset), through an event chain.  With per-kernel timing
+     * on everything stays on one stream. */
+    bool cont_pending = false; /* ev_cont = the last layout step, recorded on a lane other than the next one */
     for (uint64_t c0 = 0; c0 < nchunks; c0 += ctx->max_chunks) {
         const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
-        const uint32_t ns = 4u * nb;
-        const uint32_t *bin = in + c0 * CHK;
+        const uint32_t nlanes = ctx->timing ? 1u : (nb < ctx->lanes ? nb : ctx->lanes);
         const uint64_t bfl = (nfloats - c0 * CHK) < (uint64_t)nb * CHK ? (nfloats - c0 * CHK) : (uint64_t)nb * CHK;
-        const uint32_t fstart = (first_chunk + c0 == 0) ? 1u : 0u;
-        ctx->last_streams = ns;
-        LAUNCH("k_tile_summary", k_tile_summary, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, ctx->tsum, ctx->planes);
-        LAUNCH("k_stream_scan", k_stream_scan, dim3(ns), dim3(256), ctx->tsum, bfl, ctx->tinfo, ctx->sinfo, ctx->blkstart);
-        LAUNCH("k_histogram", k_histogram, dim3(SPS, nb, 4), dim3(64), ctx->planes, bfl, ctx->tinfo, ctx->pairhist, ctx->blkstart,
-               ctx->slideq);
-        LAUNCH("k_block_reduce", k_block_reduce, dim3(MAXBLK, ns), dim3(64), ctx->tinfo, ctx->sinfo, ctx->pairhist, ctx->blkfreq);
-        LAUNCH("k_block_index", k_block_index, dim3(1), dim3(256), ctx->sinfo, ns, ctx->blkbase);
-        LAUNCH("k_huffman", k_huffman, dim3((ns * MAXBLK + HT - 1) / HT), dim3(HT), ctx->sinfo, ns, ctx->blkbase, ctx->blkfreq,
-               ctx->blkcode, ctx->blkhdr, ctx->meta);
-        LAUNCH("k_stream_layout", k_stream_layout, dim3(ns), dim3(64), ctx->sinfo, ctx->meta, ctx->blkstart, ctx->slideq, ctx->lay);
-        LAUNCH("k_pair_bits", k_pair_bits, dim3(SPS, ns), dim3(64), ctx->sinfo, ctx->lay, ctx->pairhist, ctx->blkcode, ctx->tinfo,
-               ctx->pairbits);
-        LAUNCH("k_pair_offsets", k_pair_offsets, dim3(ns), dim3(64), ctx->sinfo, ctx->lay, ctx->tinfo, ctx->pairbits, ctx->pairoff);
-        LAUNCH("k_container", k_container, dim3(1), dim3(256), ctx->sinfo, nb, out, ctx->result, 0);
-        LAUNCH("k_zero_records", k_zero_records, dim3(2048), dim3(256), out, ctx->result);
-        LAUNCH("k_container", k_container, dim3(1), dim3(256), ctx->sinfo, nb, out, ctx->result, 1);
-        LAUNCH("k_emit", k_emit, dim3(SPS, nb, 4), dim3(64), ctx->planes, bfl, ctx->tinfo, ctx->sinfo, ctx->lay, ctx->blkstart,
-               ctx->blkcode, ctx->pairoff, out);
-        LAUNCH("k_emit_headers", k_emit_headers, dim3(MAXBLK + 1, ns), dim3(64), ctx->sinfo, ctx->lay, ctx->meta, ctx->blkhdr,
-               ctx->blkstart, out);
+        ctx->last_streams = 4u * nb;
+        uint32_t lc0[MAX_LANES + 1]; /* first chunk (inside the batch) of every lane */
+        for (uint32_t l = 0; l <= nlanes; l++) lc0[l] = (uint32_t)(((uint64_t)nb * l) / nlanes);
+        for (int phase = 0; phase < 3; phase++) {
+            for (uint32_t l = 0; l < nlanes; l++) {
+                const uint32_t cb = lc0[l], nbl = lc0[l + 1] - lc0[l];
+                const uint64_t f0 = (uint64_t)cb * CHK; /* floats of the batch before this lane */
+                const uint64_t bfll = bfl - f0 < (uint64_t)nbl * CHK ? bfl - f0 : (uint64_t)nbl * CHK;
+                const uint32_t fstart = (first_chunk + c0 + cb == 0) ? 1u : 0u;
+                hipStream_t st = ctx->lane_stream[l];
+                if (phase == 1) { /* layout: strictly in lane (= file) order */
+                    if (cont_pending) HIPCHK(hipStreamWaitEvent(st, ctx->ev_cont, 0), "wait");
+                }
+                if (int rc = compress_lane(ctx, st, phase, (int)l, 4u * cb, in + c0 * CHK + f0, bfll, nbl, mask, fstart, out)) return rc;
+                if (phase == 1) {
+                    HIPCHK(hipEventRecord(ctx->ev_cont, st), "event");
+                    cont_pending = true;
+                }
+            }
+        }
+    }
+    /* everything of the other lanes is done before the result is read back on the first */
+    for (int l = 1; l < MAX_LANES; l++) {
+        HIPCHK(hipEventRecord(ctx->ev_done[l], ctx->lane_stream[l]), "event");
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_done[l], 0), "wait");
     }
     HIPCHK(hipMemcpyAsync(ctx->h_result, ctx->result, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (compress)");
@@ -309,6 +383,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
     if (chk == 0 || chk > CHK) return fail(ctx, MRCZ_EFORMAT, "chunk size in header exceeds CHUNK_SIZE (constant.h:25)", hipSuccess);
     if (((uintptr_t)d_out & 15u) || ((uintptr_t)d_records & 3u)) return fail(ctx, MRCZ_EINVAL, "d_out must be 16-byte and d_records 4-byte aligned", hipSuccess);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t lstream = ctx->stream;
     if (int rc = ensure_planes(ctx)) return rc;
     if (!ctx->scratch) {
         /* real blocks fill at most the planes' size; false candidates and 16-byte rounding get another half */
@@ -424,6 +499,7 @@ extern "C" int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, 
     if (nwords == 0) return MRCZ_OK;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->ntimers = 0;
+    hipStream_t lstream = ctx->stream;
     LAUNCH("k_erase_bits", k_erase_bits, dim3(2048), dim3(256), (uint32_t *)d_words, nwords, first_word_index, mask_of(bits));
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (erase)");
     return MRCZ_OK;

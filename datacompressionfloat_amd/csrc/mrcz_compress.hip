@@ -644,16 +644,19 @@ __global__ __launch_bounds__(64) void k_pair_offsets(const StreamInfo *__restric
 /* ======================================================================================
  * container layout: payload offsets + the 16-byte chunk headers (workers.c:837-842, zip.c:381-391)
  * ==================================================================================== */
-/* zero the records of this batch, bytes [result[5], result[0]) of the output (rounded up at the end only: what lies
- * before belongs to the previous batch): the emit kernels OR their bit strings into it.  Clearing exactly what the
- * batch produced instead of the whole mrcz_records_bound() halves the bytes written up front. */
-__global__ __launch_bounds__(256) void k_zero_records(uint8_t *__restrict__ out, const uint64_t *__restrict__ result)
+/* zero the records one lane of a batch is about to emit, bytes [result[8 + slot], result[12 + slot]) of the output:
+ * the emit kernels OR their bit strings into it.  Exactly that range: the bytes before it belong to the previous
+ * lane or batch and the bytes after it to the next one, which may already be written (lanes run on two streams).
+ * Clearing what is produced instead of the whole mrcz_records_bound() halves the bytes written up front. */
+__global__ __launch_bounds__(256) void k_zero_records(uint8_t *__restrict__ out, const uint64_t *__restrict__ result, int slot)
 {
-    uint8_t *b = out + result[5], *e = out + result[0];
+    uint8_t *b = out + result[8 + slot], *e = out + result[12 + slot];
     uint8_t *ba = reinterpret_cast<uint8_t *>(((uintptr_t)b + 15u) & ~(uintptr_t)15u);
-    uint8_t *ea = reinterpret_cast<uint8_t *>(((uintptr_t)e + 15u) & ~(uintptr_t)15u); /* the buffer has 64 spare bytes */
-    if (ba > ea) ba = ea;
-    if (blockIdx.x == 0 && threadIdx.x < 16u && b + threadIdx.x < ba) b[threadIdx.x] = 0;
+    uint8_t *ea = reinterpret_cast<uint8_t *>((uintptr_t)e & ~(uintptr_t)15u);
+    if (ba > e) ba = e;
+    if (ea < ba) ea = ba;
+    if (blockIdx.x == 0 && threadIdx.x < 16u && b + threadIdx.x < ba) b[threadIdx.x] = 0;       /* head */
+    if (blockIdx.x == 1 && threadIdx.x < 16u && ea + threadIdx.x < e) ea[threadIdx.x] = 0;      /* tail */
     uint4 *p = reinterpret_cast<uint4 *>(ba);
     const uint64_t n = (uint64_t)(ea - ba) >> 4;
     const uint4 z = make_uint4(0, 0, 0, 0);
@@ -661,11 +664,12 @@ __global__ __launch_bounds__(256) void k_zero_records(uint8_t *__restrict__ out,
 }
 
 __global__ __launch_bounds__(256) void k_container(StreamInfo *__restrict__ sinfo, uint32_t nchunks, uint8_t *__restrict__ out,
-                                                   uint64_t *__restrict__ result /* [0] running byte offset, [1..4] per-plane zfsz, [5] where this batch starts */,
-                                                   int write_headers)
+                                                   uint64_t *__restrict__ result /* [0] running byte offset, [1..4] per-plane zfsz,
+                                                                                    [8 + slot] / [12 + slot] where this lane's records start / end */,
+                                                   int write_headers, int slot)
 {
-    /* called twice per batch: write_headers = 0 lays the batch out (payload offsets, running offset), then the
-     * records are zeroed, then write_headers = 1 stores the 16-byte chunk headers */
+    /* called twice per lane of a batch: write_headers = 0 lays the lane out (payload offsets, running offset), then
+     * its records are zeroed, then write_headers = 1 stores the 16-byte chunk headers */
     /* one thread per chunk of the batch (<= 128 chunks, records < 4 GiB) */
     __shared__ SegPair wsum[4];
     const uint32_t c = threadIdx.x;
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(256) void k_container(StreamInfo *__restrict__ sinf
         }
         v.sum = 16u + len[0] + len[1] + len[2] + len[3];
     }
-    const uint64_t base = write_headers ? result[5] : result[0];
+    const uint64_t base = write_headers ? result[8 + slot] : result[0];
     const SegPair pre = block_excl_scan(v, wsum);
     if (c < nchunks) {
         const uint64_t off = base + pre.sum;
@@ -700,7 +704,11 @@ __global__ __launch_bounds__(256) void k_container(StreamInfo *__restrict__ sinf
         }
     }
     __syncthreads();
-    if (!write_headers && c + 1 == nchunks) { result[5] = base; result[0] = base + pre.sum + v.sum; }
+    if (!write_headers && c + 1 == nchunks) {
+        result[8 + slot] = base;
+        result[12 + slot] = base + pre.sum + v.sum;
+        result[0] = base + pre.sum + v.sum;
+    }
 }
 
 /* ======================================================================================

@@ -141,6 +141,10 @@ double sim_now();
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(sizeof(**e)); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = sim_now(); return hipSuccess; }
+/* kernels run to completion at launch, in host order: cross-stream waits are satisfied by construction */
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+#define hipEventDisableTiming 2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e3); return hipSuccess; }
 static inline void __builtin_amdgcn_wave_barrier() { sim_wave_barrier(); }
