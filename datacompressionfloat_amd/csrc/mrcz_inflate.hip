@@ -32,24 +32,34 @@ __global__ void k_parse_records(const uint8_t *__restrict__ rec, uint64_t len, u
     uint64_t off = result[0]; /* where the previous batch of this call stopped (0 for the first) */
     uint64_t err = 0;
     const uint64_t nchunks = (nfloats + chk - 1) / chk;
-    for (uint64_t c = 0; c < nchunks; c++) {
+    uint64_t c = 0;
+    for (; c < nchunks; c++) {
         const uint64_t left = nfloats - c * chk;
         const uint32_t n = (uint32_t)(left < chk ? left : chk);
         if (off + 16 > len) { err = 1; break; }
         uint64_t p = off + 16;
+        DecStream d4[4];
         for (int j = 0; j < 4; j++) {
             const uint8_t *h = rec + off + 4 * j;
             const uint32_t raw = (h[3] & 0x80u) >> 7;
             const uint32_t l = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)(h[3] & 0x7fu) << 24);
-            DecStream d;
-            d.payoff = p; d.paylen = l; d.raw = raw; d.n = n; d.pad = 0;
+            d4[j].payoff = p; d4[j].paylen = l; d4[j].raw = raw; d4[j].n = n; d4[j].pad = 0;
             if (p + l > len || (raw && l < n)) err = 1;
-            ds[4 * c + j] = d;
             p += l;
         }
         if (err) break;
+        for (int j = 0; j < 4; j++) ds[4 * c + j] = d4[j];
         off = p;
     }
+    /* a malformed or truncated container: the call will fail, but the kernels queued behind this one still run.
+     * Give them empty streams (nothing to scan, decode or copy) instead of descriptors that point outside the
+     * records -- from this chunk on they are wrong or left over from an earlier call. */
+    for (; c < nchunks; c++)
+        for (int j = 0; j < 4; j++) {
+            DecStream d;
+            d.payoff = 0; d.paylen = 0; d.raw = 0; d.n = 0; d.pad = 0;
+            ds[4 * c + j] = d;
+        }
     result[0] = off;
     if (err) result[1] = err; /* sticky across the batches of a call */
 }
