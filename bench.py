@@ -184,8 +184,12 @@ def main():
         codec.set_timing(False)
         dom = max(acc, key=acc.get)
         # algorithmic bytes of one launch: what the kernel must read once + write once
+        # planes stored verbatim (RAW, zip.c:184-190) never pass through the entropy kernels: leave them out of those kernels' bytes
+        _, plane_bytes = codec.compress_device(words, args.bits, first_chunk, out=rec_bufs[0])
+        raw_planes = sum(1 for pb in plane_bytes if pb == nfloats + 4 * nchunks)
+        z_coded, n_coded = zbytes - raw_planes * nfloats, (4 - raw_planes) * nfloats
         alg = {"k_tile_summary": 8.0 * nfloats, "k_histogram": 4.0 * nfloats, "k_emit": 4.0 * nfloats + zbytes,
-               "k_blk_count": zbytes + 4.0 * nfloats, "k_blk_gather": 8.0 * nfloats, "k_inflate_par": zbytes + 4.0 * nfloats,
+               "k_blk_count": z_coded + n_coded, "k_blk_gather": 2.0 * n_coded, "k_inflate_par": z_coded + n_coded,
                "k_merge_planes": 8.0 * nfloats}.get(dom, 4.0 * nfloats + zbytes)
         achieved = alg / (acc[dom] * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
