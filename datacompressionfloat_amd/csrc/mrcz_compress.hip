@@ -985,21 +985,34 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
                             }
                             continue;
                         }
-#pragma unroll
-                        for (int j = 0; j < 16; j++) {
-                            const uint32_t byte = (wv[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                            uint32_t e = lut[byte];
-                            uint32_t val = e & 0xffffu;
-                            int nb = (int)(e >> 16);
-                            if ((Mg >> j) & 1u) {
-                                int xb, xv;
-                                const int code = len_code(match_len_at(lt.E, lt.a, lt.nextS, 16 * g + j), &xb, &xv);
-                                e = lut[257 + code];
-                                const int cl = (int)(e >> 16);
-                                val = (e & 0xffffu) | ((uint32_t)xv << cl);
-                                nb = cl + xb + (int)dbits;
+                        /* runs and literals mixed (exponent planes, masked planes): walk the lane's symbols, not its
+                         * positions -- a match covers at least three positions, so there are far fewer of them, and
+                         * the match arithmetic runs once per match instead of once per position in which any lane
+                         * of the wave happens to have one */
+                        {
+                            uint32_t rem = Sg;
+                            const uint8_t *rowb = plane + lane * ROWPAD + 16 * g;
+                            while (__ballot(rem != 0u)) {
+                                if (rem) {
+                                    const int j = __builtin_ctz(rem);
+                                    rem &= rem - 1u;
+                                    uint32_t val;
+                                    int nb;
+                                    if ((Mg >> j) & 1u) {
+                                        int xb, xv;
+                                        const int code = len_code(match_len_at(lt.E, lt.a, lt.nextS, 16 * g + j), &xb, &xv);
+                                        const uint32_t e = lut[257 + code];
+                                        const int cl = (int)(e >> 16);
+                                        val = (e & 0xffffu) | ((uint32_t)xv << cl);
+                                        nb = cl + xb + (int)dbits;
+                                    } else {
+                                        const uint32_t e = lut[rowb[j]];
+                                        val = e & 0xffffu;
+                                        nb = (int)(e >> 16);
+                                    }
+                                    packer_put(pk, val, nb);
+                                }
                             }
-                            if ((Sg >> j) & 1u) packer_put(pk, val, nb);
                         }
                     }
                 }
