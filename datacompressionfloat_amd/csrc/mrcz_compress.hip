@@ -411,7 +411,12 @@ __global__ __launch_bounds__(64) void k_histogram(const uint8_t *__restrict__ pl
                         act &= ~same;
                     }
                 }
-            } else {
+            } else if (__ballot(L != ~0ull || inA != ~0ull) == 0ull) {
+                /* every position of every lane is a literal of the current block (the interior of a coded plane): no
+                 * per-position tests, just 64 byte extracts and atomics (wave-uniform branch) */
+#pragma unroll
+                for (int i = 0; i < 64; i++) atomicAdd(&rowA[(x[i >> 2] >> (8 * (i & 3))) & 0xffu], 1u);
+            } else if (__ballot(L != 0ull) != 0ull) {
 #pragma unroll
                 for (int i = 0; i < 64; i++) {
                     if ((L >> i) & 1ull) {
