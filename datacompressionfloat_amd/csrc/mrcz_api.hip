@@ -336,7 +336,8 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
     bool cont_pending = false; /* ev_cont = the last layout step, recorded on a lane other than the next one */
     for (uint64_t c0 = 0; c0 < nchunks; c0 += ctx->max_chunks) {
         const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
-        const uint32_t nlanes = ctx->timing ? 1u : (nb < ctx->lanes ? nb : ctx->lanes);
+        /* small batches are launch-bound: a second lane doubles the launches (64 MiB: 78 -> 69 GB/s with two lanes) */
+        const uint32_t nlanes = (ctx->timing || nb < 8u) ? 1u : (nb < ctx->lanes ? nb : ctx->lanes);
         const uint64_t bfl = (nfloats - c0 * CHK) < (uint64_t)nb * CHK ? (nfloats - c0 * CHK) : (uint64_t)nb * CHK;
         ctx->last_streams = 4u * nb;
         uint32_t lc0[MAX_LANES + 1]; /* first chunk (inside the batch) of every lane */
