@@ -63,6 +63,13 @@ if "--cli-only" not in sys.argv:
     cnt = torch.poisson(torch.full((16 * 1048576,), 8.0, device=dev), generator=g)
     w3 = torch.cat([torch.zeros(256, dtype=torch.float32, device=dev), cnt]).view(torch.int32).contiguous()
     res["config3_mrc_small_64MiB_poisson"] = [measure(codec, w3, b) for b in (0, 8)]
+    del w3, cnt
+    # the same detector-count statistics at the 1 GiB size of config 2 (what a large .mrc stack looks like to the codec)
+    cnt = torch.poisson(torch.full((n - 256,), 8.0, device=dev), generator=g)
+    w4 = torch.cat([torch.zeros(256, dtype=torch.float32, device=dev), cnt]).view(torch.int32).contiguous()
+    del cnt
+    res["poisson_counts_1GiB"] = [measure(codec, w4, b) for b in (0, 8)]
+    del w4
     codec.close()
 
 # command-line tools end to end on a 1 GiB file in /dev/shm (what a user of mrc_tar sees: file I/O + PCIe + codec)
