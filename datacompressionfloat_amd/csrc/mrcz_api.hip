@@ -26,6 +26,7 @@ using namespace mrcz;
 struct mrcz_ctx {
     int device;
     uint32_t max_chunks;
+    uint32_t row_chunks;           /* chunk rows of the workspace (>= max_chunks, a multiple of the lane count) */
     hipStream_t stream;            /* everything except ...                                                     */
     hipStream_t lane_stream[MAX_LANES]; /* ... the lanes of a compress batch (see mrcz_compress_chunks); [0] = stream */
     hipEvent_t ev_start, ev_cont, ev_done[MAX_LANES];
@@ -75,6 +76,7 @@ struct mrcz_ctx {
     hipEvent_t ev0, ev1;
     /* inspection */
     uint32_t last_streams;
+    uint32_t last_nlanes, last_lc0[MAX_LANES], last_row0[MAX_LANES]; /* lanes of the last compressed batch: first chunk, first workspace row */
     uint64_t last_fallbacks;
 };
 
@@ -111,16 +113,18 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->device = device;
     ctx->max_chunks = max_batch_chunks;
     if (hipSetDevice(device) != hipSuccess) { free(ctx); return MRCZ_EHIP; }
-    const size_t ns = 4u * (size_t)max_batch_chunks;
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
     ctx->lane_stream[0] = ctx->stream;
     ctx->lanes = 2;
     if (const char *ev = getenv("MRCZ_LANES")) { const int v = atoi(ev); if (v >= 1 && v <= MAX_LANES) ctx->lanes = (uint32_t)v; }
+    /* workspace rows (one per stream): every compress lane owns a fixed range of ceil(max_chunks / lanes) chunk rows */
+    ctx->row_chunks = ctx->lanes * ((max_batch_chunks + ctx->lanes - 1u) / ctx->lanes);
+    const size_t ns = 4u * (size_t)ctx->row_chunks;
     for (int l = 1; l < MAX_LANES && e == hipSuccess; l++) e = hipStreamCreate(&ctx->lane_stream[l]);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_cont, hipEventDisableTiming);
-    for (int l = 1; l < MAX_LANES && e == hipSuccess; l++) e = hipEventCreateWithFlags(&ctx->ev_done[l], hipEventDisableTiming);
+    for (int l = 0; l < MAX_LANES && e == hipSuccess; l++) e = hipEventCreateWithFlags(&ctx->ev_done[l], hipEventDisableTiming);
     if (e == hipSuccess) e = dalloc(&ctx->tsum, ns * TPS);
     if (e == hipSuccess) e = dalloc(&ctx->tinfo, ns * TPS);
     if (e == hipSuccess) e = dalloc(&ctx->sinfo, ns);
@@ -158,7 +162,7 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_blk_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
     if (e != hipSuccess) {
         mrcz_destroy(ctx);
-        return e == hipSuccess ? MRCZ_ENOMEM : MRCZ_ENOMEM;
+        return e == hipErrorOutOfMemory ? MRCZ_ENOMEM : MRCZ_EHIP;
     }
     *out = ctx;
     return MRCZ_OK;
@@ -180,6 +184,7 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_cont) (void)hipEventDestroy(ctx->ev_cont);
+    if (ctx->ev_done[0]) (void)hipEventDestroy(ctx->ev_done[0]);
     for (int l = 1; l < MAX_LANES; l++) {
         if (ctx->ev_done[l]) (void)hipEventDestroy(ctx->ev_done[l]);
         if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
@@ -259,7 +264,7 @@ static uint32_t mask_of(int bits) { return bits >= 32 ? 0u : (0xFFFFFFFFu << bit
 static int ensure_planes(mrcz_ctx *ctx)
 {
     if (ctx->planes) return MRCZ_OK;
-    hipError_t e = hipMalloc((void **)&ctx->planes, (size_t)4 * ctx->max_chunks * CHK);
+    hipError_t e = hipMalloc((void **)&ctx->planes, (size_t)4 * ctx->row_chunks * CHK);
     if (e != hipSuccess) { ctx->planes = NULL; return fail(ctx, MRCZ_ENOMEM, "plane workspace", e); }
     return MRCZ_OK;
 }
@@ -334,12 +339,27 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
      * the layout step is ordered across lanes (running byte offset), through an event chain.  With per-kernel timing
      * on everything stays on one stream. */
     bool cont_pending = false; /* ev_cont = the last layout step, recorded on a lane other than the next one */
+    /* Workspace rows are reused by every batch, and nothing but the layout chain orders the lane streams.  A row must
+     * therefore always be touched by the SAME stream: lane l owns the fixed row range that starts at chunk row l * pc
+     * (pc = rows per lane for the context's lane count), whatever the size of the batch.  Where the lane count changes
+     * between two batches (the last, short batch of a call runs as one lane) the row ownership changes too, and every
+     * lane stream first waits for all of the previous batch. */
+    const uint32_t pc = (ctx->max_chunks + ctx->lanes - 1u) / ctx->lanes;
+    uint32_t prev_lanes = 0;
     for (uint64_t c0 = 0; c0 < nchunks; c0 += ctx->max_chunks) {
         const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
         /* small batches are launch-bound: a second lane doubles the launches (64 MiB: 78 -> 69 GB/s with two lanes) */
         const uint32_t nlanes = (ctx->timing || nb < 8u) ? 1u : (nb < ctx->lanes ? nb : ctx->lanes);
         const uint64_t bfl = (nfloats - c0 * CHK) < (uint64_t)nb * CHK ? (nfloats - c0 * CHK) : (uint64_t)nb * CHK;
         ctx->last_streams = 4u * nb;
+        ctx->last_nlanes = nlanes;
+        if (prev_lanes && prev_lanes != nlanes) {
+            for (uint32_t l = 0; l < prev_lanes; l++) HIPCHK(hipEventRecord(ctx->ev_done[l], ctx->lane_stream[l]), "event");
+            for (uint32_t l = 0; l < nlanes; l++)
+                for (uint32_t k = 0; k < prev_lanes; k++)
+                    if (k != l) HIPCHK(hipStreamWaitEvent(ctx->lane_stream[l], ctx->ev_done[k], 0), "wait");
+        }
+        prev_lanes = nlanes;
         uint32_t lc0[MAX_LANES + 1]; /* first chunk (inside the batch) of every lane */
         for (uint32_t l = 0; l <= nlanes; l++) lc0[l] = (uint32_t)(((uint64_t)nb * l) / nlanes);
         for (int phase = 0; phase < 3; phase++) {
@@ -352,7 +372,9 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
                 if (phase == 1) { /* layout: strictly in lane (= file) order */
                     if (cont_pending) HIPCHK(hipStreamWaitEvent(st, ctx->ev_cont, 0), "wait");
                 }
-                if (int rc = compress_lane(ctx, st, phase, (int)l, 4u * cb, in + c0 * CHK + f0, bfll, nbl, mask, fstart, out)) return rc;
+                const uint32_t row0 = nlanes == 1u ? 0u : 4u * l * pc; /* first workspace row (stream slot) of this lane */
+                ctx->last_lc0[l] = cb; ctx->last_row0[l] = row0;
+                if (int rc = compress_lane(ctx, st, phase, (int)l, row0, in + c0 * CHK + f0, bfll, nbl, mask, fstart, out)) return rc;
                 if (phase == 1) {
                     HIPCHK(hipEventRecord(ctx->ev_cont, st), "event");
                     cont_pending = true;
@@ -522,6 +544,11 @@ extern "C" int64_t mrcz_debug_fallbacks(const mrcz_ctx_t *ctx) { return ctx ? (i
 extern "C" int mrcz_debug_blocks(mrcz_ctx_t *ctx, uint32_t stream, mrcz_block_info_t *blocks, uint32_t max_blocks)
 {
     if (!ctx || stream >= ctx->last_streams) return MRCZ_EINVAL;
+    {   /* stream number inside the batch -> workspace row of the lane that coded it */
+        uint32_t l = 0;
+        while (l + 1 < ctx->last_nlanes && (stream >> 2) >= ctx->last_lc0[l + 1]) l++;
+        stream = ctx->last_row0[l] + (stream - 4u * ctx->last_lc0[l]);
+    }
     StreamInfo si;
     if (hipMemcpy(&si, ctx->sinfo + stream, sizeof(si), hipMemcpyDeviceToHost) != hipSuccess) return MRCZ_EHIP;
     uint32_t nb = si.nblk;

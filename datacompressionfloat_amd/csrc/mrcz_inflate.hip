@@ -44,7 +44,9 @@ __global__ void k_parse_records(const uint8_t *__restrict__ rec, uint64_t len, u
             const uint32_t raw = (h[3] & 0x80u) >> 7;
             const uint32_t l = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)(h[3] & 0x7fu) << 24);
             d4[j].payoff = p; d4[j].paylen = l; d4[j].raw = raw; d4[j].n = n; d4[j].pad = 0;
-            if (p + l > len || (raw && l < n)) err = 1;
+            /* a deflate stream of n bytes is never longer than n + n/8 + a few bytes (stored blocks: 5 per 65535); anything
+             * larger is not a plane of this container (and 8 * paylen must stay below 2^32 for the bit positions) */
+            if (p + l > len || (raw && l < n) || (!raw && l > CHK + (CHK >> 3) + 1024u)) err = 1;
             p += l;
         }
         if (err) break;

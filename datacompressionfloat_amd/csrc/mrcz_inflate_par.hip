@@ -1542,12 +1542,15 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
     __syncthreads();
     if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
     for (;;) {
-        if (sh.status != 0) break;
-        if (sh.op >= sv.n) { if (tid == 0) sh.status = 1; __syncthreads(); break; }
+        /* every thread reads the exit condition between two barriers, so all waves leave in the same iteration */
+        const bool done = sh.status != 0 || sh.op >= sv.n;
+        __syncthreads();
+        if (done) break;
         if (dbg && tid == 0) sh.acc[10]++;
         decode_one_block<MODE_FINAL>(sh, sv, tid, dbg, ScratchOut(), nullptr, 0u);
         __syncthreads();
     }
+    if (tid == 0 && sh.status == 0) sh.status = 1; /* left because the plane is complete */
     __syncthreads();
     if (tid == 0) {
         if (sh.status == 1 && sh.op != sv.n) sh.status = 2;

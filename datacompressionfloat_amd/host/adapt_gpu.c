@@ -103,6 +103,38 @@ int init_file_container_ex(file_container_t *fc, const char *ifcFile, const char
     return 0;
 }
 
+/* adapt.c:147-178: the older list form still used by the reference's own front-end (src/main/mrc_tarx.c:192,197):
+ * source j is line j of the list file, destination j is "<prefix><j>.<suffix>" */
+int init_file_container(file_container_t *fc, char *file_list_descriptor, char *prefix, char *suffix)
+{
+    FILE *fp = fopen(file_list_descriptor, "r");
+    if (!fp) {
+        fprintf(stderr, "[%s:%d] Error: Open File Failed: [ %s ]\n", __FILE__, __LINE__, file_list_descriptor);
+        exit(-1); /* adapt.c:100-105 */
+    }
+    char line[1024];
+    int lines = 0;
+    while (fgets(line, sizeof(line), fp)) lines++;
+    rewind(fp);
+    fc->idx = 0;
+    fc->size = 0;
+    fc->fileNum = lines;
+    fc->srcs = (char **)calloc((size_t)(lines ? lines : 1), sizeof(char *));
+    fc->dsts = (char **)calloc((size_t)(lines ? lines : 1), sizeof(char *));
+    int j = 0;
+    while (j < lines && fgets(line, sizeof(line), fp)) {
+        rstrip(line);
+        fc->srcs[j] = strdup(line);
+        fc->dsts[j] = (char *)malloc(strlen(prefix) + strlen(suffix) + 32);
+        sprintf(fc->dsts[j], "%s%d.%s", prefix, j, suffix);
+        j++;
+    }
+    fc->size = j;
+    fclose(fp);
+    pthread_mutex_init(&fc->lock, NULL);
+    return 0;
+}
+
 void print_file_container_info(file_container_t *fc) /* adapt.c:115-123 */
 {
     for (int i = 0; i < fc->size; i++) printf("%s:%s\n", fc->srcs[i], fc->dsts[i]);

@@ -63,7 +63,7 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
 extern int isTestThroughput; /* src/core/workers.c:39: 1 = skip all output writes (-d 1) */
 
 /* Extra knobs of the GPU implementation (not in the reference): HIP device used by the calling
- * thread (default 0) and chunks per device batch (default 16 = 384 MiB of input). */
+ * thread (default 0) and chunks per device batch (default 8 = 192 MiB of input). */
 void mrcz_workers_set_device(int device);
 void mrcz_workers_set_batch_chunks(int chunks);
 
@@ -78,6 +78,7 @@ typedef struct _file_container_t {
     int fileNum;
     pthread_mutex_t lock;
 } file_container_t;
+int init_file_container(file_container_t *file_container, char *file_list_descriptor, char *prefix, char *suffix); /* adapt.h:43 */
 int init_file_container_ex(file_container_t *fnames, const char *ifcFile, const char *outputDir, char *opType);
 void free_file_container(file_container_t *file_container);
 void print_file_container_info(file_container_t *fnames);

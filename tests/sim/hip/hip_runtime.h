@@ -38,6 +38,7 @@ typedef struct sim_stream_s *hipStream_t;
 typedef struct sim_event_s { double t; } *hipEvent_t;
 #define hipSuccess 0
 #define hipErrorInvalidValue 1
+#define hipErrorOutOfMemory 2
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 
 struct uint4 { unsigned x, y, z, w; };

@@ -112,3 +112,60 @@ def test_erasebytes_tool_matches_the_reference_tool(tmp_path):
             rdst = tmp_path / "ref.mrc"
             r = _run([ref, "-i", str(src), "-o", str(rdst), "-b", str(bits)])
             assert r.returncode == 0 and rdst.read_bytes() == got
+
+
+def _accounting_row(stdout: str):
+    """(allFileSize, allZipFileSize) from the row print_context_info writes under its four column titles (common.c:66-90)"""
+    lines = stdout.splitlines()
+    for i, l in enumerate(lines):
+        if l.startswith("[Original File Size(Bytes)]"):
+            f = lines[i + 1].split()
+            return int(f[0]), int(f[1])
+    raise AssertionError("no accounting row in:\n" + stdout)
+
+
+@pytest.mark.skipif(util.ref_binary("mrc_tar_c") is None, reason="oracle/_ref not present on this box")
+def test_ctx_accounting_matches_the_reference(tmp_path):
+    """SURVEY a15: zip -> allZipFileSize == container size - 17 (sum of payload + 4-byte plane headers, workers.c:870-873);
+    unzip -> allFileSize == 4 * floats, allZipFileSize == payload bytes (workers.c:679-685).  Same numbers as the
+    reference binary prints on the same input."""
+    exe, ref = os.path.join(BIN, "mrc_tar"), util.ref_binary("mrc_tar_c")
+    n = util.CHUNK + 54321
+    w = util.gauss_words(n, seed=5)
+    src, z, zr, b = (tmp_path / x for x in ("in.mrc", "gpu.zip", "ref.zip", "back"))
+    src.write_bytes(w.tobytes() + b"\x01\x02")          # a file size that is not a multiple of 4
+    r = _run([exe, "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip"])
+    rr = _run([ref, "-i", str(src), "-o", str(zr), "-b", "8", "-t", "zip"])
+    assert r.returncode == 0 and rr.returncode == 0
+    fs, zs = _accounting_row(r.stdout)
+    assert (fs, zs) == (4 * n + 2, os.path.getsize(z) - 17)
+    assert (fs, zs) == _accounting_row(rr.stdout)
+    r = _run([exe, "-i", str(z), "-o", str(b), "-t", "unzip"])
+    rr = _run([ref, "-i", str(zr), "-o", str(tmp_path / "rb"), "-t", "unzip"])
+    assert r.returncode == 0 and rr.returncode == 0
+    fs, zs = _accounting_row(r.stdout)
+    assert (fs, zs) == (4 * n, os.path.getsize(z) - 17 - 16 * 2)
+    assert (fs, zs) == _accounting_row(rr.stdout)
+
+
+@pytest.mark.skipif(util.ref_binary("mrc_tar_refmain_gpu") is None, reason="oracle/_ref not present on this box")
+def test_reference_front_ends_run_on_the_drop_in_library(tmp_path, oracle):
+    """the reference's own src/main/mrc_tar.c and mrc_tarx.c, compiled unchanged and linked against
+    libmrcz_workers.so (oracle/Makefile), produce the reference's bytes with the codec on the GPU."""
+    w = util.gauss_words(200000, seed=9)
+    src, z, b = tmp_path / "in.mrc", tmp_path / "o.zip", tmp_path / "b.mrc"
+    src.write_bytes(w.tobytes())
+    exe = util.ref_binary("mrc_tar_refmain_gpu")
+    r = _run([exe, "-i", str(src), "-o", str(z), "-b", "12", "-t", "zip"])
+    assert r.returncode == 0, r.stderr
+    assert z.read_bytes() == oracle.compress(w.tobytes(), 12)
+    assert _run([exe, "-i", str(z), "-o", str(b), "-t", "unzip"]).returncode == 0
+    assert b.read_bytes() == util.erase_expected(w, 12).tobytes()
+    # mrc_tarx main(): list file in, <out>/<name>.mrc.zip out (adapt.c:297-311)
+    exx = util.ref_binary("mrc_tarx_refmain_gpu")
+    lst, zdir = tmp_path / "l.txt", tmp_path / "zz"
+    zdir.mkdir()
+    lst.write_text(str(src) + "\n")
+    r = _run([exx, "-i", str(lst), "-t", "zip", "-o", str(zdir), "-b", "12", "-n", "1"])
+    assert r.returncode == 0, r.stderr
+    assert (zdir / "in.mrc.zip").read_bytes() == oracle.compress(w.tobytes(), 12)

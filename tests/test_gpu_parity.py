@@ -127,6 +127,32 @@ def test_batches_smaller_than_the_volume(codec):
     small.close()
 
 
+def test_two_lane_batches_with_a_short_last_batch(codec):
+    """Two compress lanes (batches of >= 8 chunks run as two streams) over several batches whose last one is shorter:
+    workspace rows must never be shared by two streams at a time.  26 chunks through a 16-chunk context = one batch of
+    16 (lanes of 8 + 8) and one of 10 (5 + 5); a noisy first part and an all-zero second part make the lanes finish at
+    very different times.  Same bytes as ONE batch, and as 7-chunk batches (single lane)."""
+    import torch
+    n = 26 * util.CHUNK - 777
+    g = torch.Generator(device="cuda").manual_seed(99)
+    words = torch.empty(n, dtype=torch.float32, device="cuda").normal_(10.0, 3.0, generator=g).view(torch.int32)
+    words[13 * util.CHUNK + 5:] = 0
+    one = type(codec)(0, max_batch_chunks=26)
+    ref, ref_planes = one.compress_device(words, 4, 0)
+    ref = ref.clone()
+    one.close()
+    for mb in (16, 12, 7):
+        c = type(codec)(0, max_batch_chunks=mb)
+        for _ in range(3):
+            rec, planes = c.compress_device(words, 4, 0)
+            assert planes == ref_planes and rec.numel() == ref.numel() and torch.equal(rec, ref), mb
+        out, _ = c.uncompress_device(rec, n)
+        exp = words.clone()
+        c.erase_bits_device(exp, 4, 0)
+        assert torch.equal(out, exp) and c.last_fallbacks() == 0
+        c.close()
+
+
 def test_empty_and_invalid(codec):
     from datacompressionfloat_amd import MrczError
     assert codec.zip_bytes(b"", 0) == b""
