@@ -30,6 +30,11 @@ struct mrcz_ctx {
     hipStream_t stream;            /* everything except ...                                                     */
     hipStream_t lane_stream[MAX_LANES]; /* ... the lanes of a compress batch (see mrcz_compress_chunks); [0] = stream */
     hipEvent_t ev_start, ev_cont, ev_done[MAX_LANES];
+    hipEvent_t ev_stream[MAX_LANES]; /* lane l's summary + histogram passes are done */
+    int stagger;                   /* lanes start one after the other (each once the previous one's streaming passes are done), so that
+                                    * their Huffman kernels -- one tree's latency long, nearly idle machine -- run under the other lanes'
+                                    * bandwidth-bound passes instead of side by side */
+    int huff_ht;                   /* trees per Huffman workgroup (16 / 32 / 48) */
     uint32_t lanes;                /* lanes per compress batch: 2 measured best (1: 292, 2: 306, 3: 307, 4: 229 GB/s -- with four
                                     * Huffman kernels resident their 72 KB workgroups starve the streaming kernels of LDS);
                                     * MRCZ_LANES overrides it for experiments */
@@ -56,7 +61,9 @@ struct mrcz_ctx {
     Cand *cands;           /* block-start candidates, MAXCAND per stream */
     uint32_t *ncand;       /* [ns] candidate counts, then [ns + 1] prefix, then job counter */
     uint32_t *candbase;
-    BlkJob *jobs, *jobs_tmp;
+    Seg *segs;             /* where the plane bytes of every decoded stream are (MAXSEG per stream) */
+    uint32_t *nseg;
+    uint16_t *segidx;      /* first segment of every merge tile (MTILES per stream) */
     uint8_t *scratch;      /* speculatively decoded blocks wait here for their place in the plane; allocated on first use */
     uint64_t scratch_bytes;
     HdrCache *hdrs;        /* decoded dynamic headers, row = stream * MAXCAND + candidate slot */
@@ -64,7 +71,7 @@ struct mrcz_ctx {
     uint2 *rawlist;        /* signature survivors awaiting full header validation */
     uint32_t rawcap;
     uint32_t *njobs;
-    uint32_t *h_counts;    /* pinned: totals read back between the decode stages */
+    uint32_t blk_grid;     /* workgroups of the persistent block decoder */
     unsigned long long *dbgphase; /* 8 counters per stream when phase profiling is on */
     int phase_profile;
     uint8_t *planes;       /* byte planes of one batch (stream s at s * CHK), both directions; allocated on first use */
@@ -118,6 +125,12 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->lane_stream[0] = ctx->stream;
     ctx->lanes = 2;
     if (const char *ev = getenv("MRCZ_LANES")) { const int v = atoi(ev); if (v >= 1 && v <= MAX_LANES) ctx->lanes = (uint32_t)v; }
+    {   /* the block decoder runs as a fixed grid of three workgroups per CU (its LDS footprint admits exactly three) */
+        hipDeviceProp_t prop;
+        ctx->blk_grid = 768;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->blk_grid = 3u * (uint32_t)prop.multiProcessorCount;
+        if (const char *ev = getenv("MRCZ_BLK_GRID")) { const int v = atoi(ev); if (v >= 1 && v <= 65535) ctx->blk_grid = (uint32_t)v; }
+    }
     /* workspace rows (one per stream): every compress lane owns a fixed range of ceil(max_chunks / lanes) chunk rows */
     ctx->row_chunks = ctx->lanes * ((max_batch_chunks + ctx->lanes - 1u) / ctx->lanes);
     const size_t ns = 4u * (size_t)ctx->row_chunks;
@@ -125,6 +138,11 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_cont, hipEventDisableTiming);
     for (int l = 0; l < MAX_LANES && e == hipSuccess; l++) e = hipEventCreateWithFlags(&ctx->ev_done[l], hipEventDisableTiming);
+    for (int l = 0; l < MAX_LANES && e == hipSuccess; l++) e = hipEventCreateWithFlags(&ctx->ev_stream[l], hipEventDisableTiming);
+    ctx->stagger = 1;
+    ctx->huff_ht = 48;
+    if (const char *ev = getenv("MRCZ_STAGGER")) ctx->stagger = atoi(ev) ? 1 : 0;
+    if (const char *ev = getenv("MRCZ_HT")) { const int v = atoi(ev); if (v == 16 || v == 32 || v == 48) ctx->huff_ht = v; }
     if (e == hipSuccess) e = dalloc(&ctx->tsum, ns * TPS);
     if (e == hipSuccess) e = dalloc(&ctx->tinfo, ns * TPS);
     if (e == hipSuccess) e = dalloc(&ctx->sinfo, ns);
@@ -145,14 +163,14 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->cands, ns * MAXCAND);
     if (e == hipSuccess) e = dalloc(&ctx->ncand, ns);
     if (e == hipSuccess) e = dalloc(&ctx->candbase, ns + 1);
-    if (e == hipSuccess) e = dalloc(&ctx->jobs, ns * MAXCAND);
-    if (e == hipSuccess) e = dalloc(&ctx->jobs_tmp, ns * MAXCAND);
-    if (e == hipSuccess) e = dalloc(&ctx->njobs, 4 + RAW_SEGS); /* [0] jobs, [2] scratch top, [4..] raw list segment counts */
+    if (e == hipSuccess) e = dalloc(&ctx->segs, ns * MAXSEG);
+    if (e == hipSuccess) e = dalloc(&ctx->nseg, ns);
+    if (e == hipSuccess) e = dalloc(&ctx->segidx, ns * MTILES);
+    if (e == hipSuccess) e = dalloc(&ctx->njobs, 4 + RAW_SEGS); /* [0] candidate dequeue counter, [2] scratch top, [4..] raw list segment counts */
     if (e == hipSuccess) e = dalloc(&ctx->hdrs, ns * MAXCAND);
     if (e == hipSuccess) e = hipMemset(ctx->hdrs, 0, ns * MAXCAND * sizeof(HdrCache));
     ctx->rawcap = (uint32_t)(ns * 16384u);
     if (e == hipSuccess) e = dalloc(&ctx->rawlist, ctx->rawcap);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counts, 4 * sizeof(uint32_t));
     if (e == hipSuccess) e = dalloc(&ctx->dbgphase, ns * 40);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
@@ -176,8 +194,8 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     (void)hipFree(ctx->tsum); (void)hipFree(ctx->tinfo); (void)hipFree(ctx->sinfo); (void)hipFree(ctx->blkstart);
     (void)hipFree(ctx->slideq); (void)hipFree(ctx->pairhist); (void)hipFree(ctx->blkfreq); (void)hipFree(ctx->blkcode);
     (void)hipFree(ctx->blkhdr); (void)hipFree(ctx->meta); (void)hipFree(ctx->lay); (void)hipFree(ctx->pairbits);
-    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobs); (void)hipFree(ctx->jobs_tmp); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->scratch); (void)hipFree(ctx->hdrs); (void)hipFree(ctx->njobs);
-    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts); (void)hipFree(ctx->dbgphase);
+    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->segs); (void)hipFree(ctx->nseg); (void)hipFree(ctx->segidx); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->scratch); (void)hipFree(ctx->hdrs); (void)hipFree(ctx->njobs);
+    (void)hipFree(ctx->dbgphase);
     (void)hipFree(ctx->planes);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -185,6 +203,7 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_cont) (void)hipEventDestroy(ctx->ev_cont);
     if (ctx->ev_done[0]) (void)hipEventDestroy(ctx->ev_done[0]);
+    for (int l = 0; l < MAX_LANES; l++) if (ctx->ev_stream[l]) (void)hipEventDestroy(ctx->ev_stream[l]);
     for (int l = 1; l < MAX_LANES; l++) {
         if (ctx->ev_done[l]) (void)hipEventDestroy(ctx->ev_done[l]);
         if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
@@ -298,7 +317,11 @@ static int compress_lane(mrcz_ctx *ctx, hipStream_t lstream, int phase, int slot
         LAUNCH("k_histogram", k_histogram, dim3(SPS, nb, 4), dim3(64), planes, bfl, tinfo, pairhist, blkstart, slideq);
         LAUNCH("k_block_reduce", k_block_reduce, dim3(MAXBLK, ns), dim3(64), tinfo, sinfo, pairhist, blkfreq);
         LAUNCH("k_block_index", k_block_index, dim3(1), dim3(256), sinfo, ns, blkbase);
-        LAUNCH("k_huffman", k_huffman, dim3((ns * MAXBLK + HT - 1) / HT), dim3(HT), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta);
+        if (ctx->stagger) HIPCHK(hipEventRecord(ctx->ev_stream[slot], lstream), "event"); /* this lane's streaming passes are done: the next lane may start */
+        if (ctx->huff_ht == 16) LAUNCH("k_huffman", k_huffman<16>, dim3((ns * MAXBLK + 15) / 16), dim3(16), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta);
+        else if (ctx->huff_ht == 32) LAUNCH("k_huffman", k_huffman<32>, dim3((ns * MAXBLK + 31) / 32), dim3(32), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta);
+        else LAUNCH("k_huffman", k_huffman<48>, dim3((ns * MAXBLK + 47) / 48), dim3(48), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta);
+
         LAUNCH("k_stream_layout", k_stream_layout, dim3(ns), dim3(64), sinfo, meta, blkstart, slideq, lay);
         LAUNCH("k_pair_bits", k_pair_bits, dim3(SPS, ns), dim3(64), sinfo, lay, pairhist, blkcode, tinfo, pairbits);
         LAUNCH("k_pair_offsets", k_pair_offsets, dim3(ns), dim3(64), sinfo, lay, tinfo, pairbits, pairoff);
@@ -346,6 +369,7 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
      * lane stream first waits for all of the previous batch. */
     const uint32_t pc = (ctx->max_chunks + ctx->lanes - 1u) / ctx->lanes;
     uint32_t prev_lanes = 0;
+    int stream_pending = -1; /* lane whose ev_stream the next lane's first pass waits for */
     for (uint64_t c0 = 0; c0 < nchunks; c0 += ctx->max_chunks) {
         const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
         /* small batches are launch-bound: a second lane doubles the launches (64 MiB: 78 -> 69 GB/s with two lanes) */
@@ -371,6 +395,12 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
                 hipStream_t st = ctx->lane_stream[l];
                 if (phase == 1) { /* layout: strictly in lane (= file) order */
                     if (cont_pending) HIPCHK(hipStreamWaitEvent(st, ctx->ev_cont, 0), "wait");
+                }
+                if (phase == 0 && ctx->stagger && nlanes > 1) {
+                    /* start after the streaming passes of the lane submitted just before this one (the last lane of the
+                     * previous batch for lane 0) */
+                    if (stream_pending >= 0 && stream_pending != (int)l) HIPCHK(hipStreamWaitEvent(st, ctx->ev_stream[stream_pending], 0), "wait");
+                    stream_pending = (int)l;
                 }
                 const uint32_t row0 = nlanes == 1u ? 0u : 4u * l * pc; /* first workspace row (stream slot) of this lane */
                 ctx->last_lc0[l] = cb; ctx->last_row0[l] = row0;
@@ -427,10 +457,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
         HIPCHK(hipMemsetAsync(ctx->ncand, 0, ns * sizeof(uint32_t), ctx->stream), "memset ncand");
         HIPCHK(hipMemsetAsync(ctx->njobs, 0, (4 + RAW_SEGS) * sizeof(uint32_t), ctx->stream), "memset njobs");
         if (ctx->phase_profile == 2) HIPCHK(hipMemsetAsync(ctx->dbgphase, 0, (size_t)ns * 40 * sizeof(unsigned long long), ctx->stream), "memset dbg");
-        if (ctx->phase_profile == 1) {
-            /* profiling vehicle: every stream through the sequential-chain kernel with phase counters */
-            HIPCHK(hipMemsetAsync(ctx->fallback, 0xff, ns * sizeof(uint32_t), ctx->stream), "memset fallback");
-        } else {
+        if (ctx->phase_profile != 1) { /* (1 = profiling vehicle: every stream through the sequential-chain kernel with phase counters) */
             /* block-parallel path: find block starts, size every candidate block, close the chains, write */
             ctx->calltag = ctx->calltag * 0x01000193u + 0x9e3779b9u;
             LAUNCH("k_scan_candidates", k_scan_candidates, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(64), rec, len,
@@ -438,25 +465,18 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
             LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 4,
                    ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag);
             LAUNCH("k_cand_index", k_cand_index, dim3(1), dim3(256), ctx->ncand, ns, ctx->candbase);
-            HIPCHK(hipMemcpyAsync(ctx->h_counts, ctx->candbase + ns, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy ncand");
-            HIPCHK(hipStreamSynchronize(ctx->stream), "sync (candidates)");
-            const uint32_t total = ctx->h_counts[0];
-            if (total)
-                LAUNCH_S("k_blk_count", k_blk_count, dim3(total), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ns, ctx->candbase,
-                         ctx->cands, ctx->scratch, ctx->njobs + 2, (uint32_t)(ctx->scratch_bytes >> 4), ctx->hdrs, ctx->calltag,
-                         ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL);
-            LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->candbase, ctx->jobs, ctx->jobs_tmp, ctx->njobs, ctx->fallback);
-            HIPCHK(hipMemcpyAsync(ctx->h_counts + 1, ctx->njobs, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream), "copy njobs");
-            HIPCHK(hipStreamSynchronize(ctx->stream), "sync (chains)");
-            const uint32_t njobs = ctx->h_counts[1];
-            if (njobs)
-                LAUNCH("k_blk_gather", k_blk_gather, dim3(njobs, GATHER_PARTS), dim3(256), rec, ctx->dstreams, ctx->jobs, ctx->cands, ctx->fallback,
-                       ctx->scratch, ctx->planes);
+            /* fixed grid: the workgroups pull candidate numbers from ctx->njobs[0] until it passes candbase[ns] (no read-back) */
+            LAUNCH_S("k_blk_count", k_blk_count, dim3(ctx->blk_grid), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ns, ctx->candbase,
+                     ctx->cands, ctx->scratch, ctx->njobs + 2, (uint32_t)(ctx->scratch_bytes >> 4), ctx->hdrs, ctx->calltag, ctx->njobs,
+                     ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL);
         }
+        LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->segs, ctx->nseg, ctx->segidx,
+               ctx->fallback, ctx->phase_profile == 1 ? 1u : 0u);
         LAUNCH_S("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
                  ctx->fallback, ctx->phase_profile == 1 ? ctx->dbgphase : (unsigned long long *)NULL);
         LAUNCH("k_inflate_seq", k_inflate, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
-        LAUNCH("k_merge_planes", k_merge_planes, dim3(1024, nb), dim3(256), ctx->planes, rec, ctx->dstreams, bfl, chk, out + c0 * chk);
+        LAUNCH("k_merge_segments", k_merge_segments, dim3(512, nb), dim3(256), rec, ctx->scratch, ctx->planes, ctx->segs, ctx->nseg, ctx->segidx, bfl,
+               chk, out + c0 * chk);
     }
     HIPCHK(hipMemcpyAsync(ctx->h_result, ctx->result, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (uncompress)");

@@ -18,7 +18,8 @@
 
 namespace mrcz {
 
-constexpr int HT = 48;        /* trees (threads) per workgroup: 48 x 1.5 KB = 72 KB of LDS, two workgroups per CU */
+/* HT = trees (threads) per workgroup, a template parameter: 1.5 KB of LDS per tree.  48 (72 KB, two workgroups per CU) packs a
+ * wave best; 16 (24 KB) leaves LDS room for the streaming kernels of the other compress lanes that run under the trees. */
 constexpr int LELEMS = 286;
 constexpr int BLELEMS = 19;
 constexpr int HSLOTS = 288;
@@ -29,7 +30,7 @@ constexpr int HSLOTS = 288;
  *    heap frees at that very merge: record i = n_i | m_i << 10 lives in slot n0 - i, and later also carries the
  *    code length of internal node i in bits 20..24;
  *  - the bit-length tree's arrays reuse the heap region once the literal/length tree is finished. */
-struct TreeMem {
+template <int HT> struct TreeMem {
     uint32_t heap[HSLOTS * HT];
     uint8_t leaflen[HSLOTS * HT];   /* literal/length code lengths */
     uint16_t blcount[16 * HT];
@@ -50,7 +51,7 @@ struct TreeMem {
  * minimum: nodes are addressed by their element offset o = node * HT (child = 2 o, no multiplies), both children are
  * always read (the offset of a missing right child is clamped) so the two LDS reads are independent, and
  * smaller(a, b) = (a >> 10) <= (b >> 10) is evaluated as a <= (b | 1023). */
-__device__ __forceinline__ void sift_down(uint32_t *heap, int tid, int heap_len, int k, uint32_t v)
+template <int HT> __device__ __forceinline__ void sift_down(uint32_t *heap, int tid, int heap_len, int k, uint32_t v)
 {
     uint32_t *hp = heap + tid;
     const int lim = heap_len * HT;
@@ -70,27 +71,27 @@ __device__ __forceinline__ void sift_down(uint32_t *heap, int tid, int heap_len,
 
 /* heap holds n0 leaf keys (1-based).  Runs zlib's merge loop; returns the number of merges.  Merge i removes
  * n_i then m_i and creates internal node elems + i; its record lands in slot n0 - i. */
-__device__ __forceinline__ int merge_loop(uint32_t *heap, int tid, int n0, int elems)
+template <int HT> __device__ __forceinline__ int merge_loop(uint32_t *heap, int tid, int n0, int elems)
 {
-    for (int k = n0 / 2; k >= 1; k--) sift_down(heap, tid, n0, k, heap[k * HT + tid]);
+    for (int k = n0 / 2; k >= 1; k--) sift_down<HT>(heap, tid, n0, k, heap[k * HT + tid]);
     int heap_len = n0, it = 0;
     do {
         const uint32_t nkey = heap[1 * HT + tid];
         const uint32_t lastv = heap[heap_len * HT + tid];
         heap_len--;
-        sift_down(heap, tid, heap_len, 1, lastv);
+        sift_down<HT>(heap, tid, heap_len, 1, lastv);
         const uint32_t mkey = heap[1 * HT + tid];
         heap[(heap_len + 1) * HT + tid] = (nkey & 0x3ffu) | ((mkey & 0x3ffu) << 10);
         const uint32_t f = (nkey >> 16) + (mkey >> 16);
         const uint32_t dn = (nkey >> 10) & 63u, dm = (mkey >> 10) & 63u;
         const uint32_t d = (dn >= dm ? dn : dm) + 1u;
-        sift_down(heap, tid, heap_len, 1, (f << 16) | (d << 10) | (uint32_t)(elems + it));
+        sift_down<HT>(heap, tid, heap_len, 1, (f << 16) | (d << 10) | (uint32_t)(elems + it));
         it++;
     } while (heap_len >= 2);
     return it;
 }
 /* h-th node in zlib's removal order (n_0, m_0, n_1, m_1, ...) */
-__device__ __forceinline__ int removed_node(const uint32_t *heap, int tid, int n0, int h)
+template <int HT> __device__ __forceinline__ int removed_node(const uint32_t *heap, int tid, int n0, int h)
 {
     const uint32_t w = heap[(n0 - (h >> 1)) * HT + tid];
     return (int)((h & 1) ? (w >> 10) & 0x3ffu : w & 0x3ffu);
@@ -150,12 +151,12 @@ __global__ __launch_bounds__(256) void k_block_index(const StreamInfo *__restric
     if (threadIdx.x == 0) blkbase[nstreams] = carry;
 }
 
-__global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ sinfo, uint32_t nstreams,
+template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ sinfo, uint32_t nstreams,
                                                 const uint32_t *__restrict__ blkbase, const uint16_t *__restrict__ blkfreq,
                                                 uint32_t *__restrict__ blkcode, uint32_t *__restrict__ blkhdr,
                                                 BlkMeta *__restrict__ meta)
 {
-    __shared__ TreeMem tm;
+    __shared__ TreeMem<HT> tm;
     const int tid = threadIdx.x;
     /* all-zero code lengths for every tree of the workgroup (one wave: cooperative, before anyone leaves) */
     for (int w = tid; w < HSLOTS * HT / 4; w += HT) reinterpret_cast<uint32_t *>(tm.leaflen)[w] = 0;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
         }
     }
     /* a block always holds >= 1 symbol besides END_BLOCK, so n >= 2 (zlib's "force 2 codes" rule never fires) */
-    const int niter = merge_loop(tm.heap, tid, n, LELEMS);
+    const int niter = merge_loop<HT>(tm.heap, tid, n, LELEMS);
 
     int overflow = 0;
     for (int i = 0; i < 16; i++) BLCOUNT(i) = 0;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
         for (int bits = 15; bits != 0; bits--) {
             int cnt = BLCOUNT(bits);
             while (cnt != 0) {
-                const int m = removed_node(tm.heap, tid, n, h);
+                const int m = removed_node<HT>(tm.heap, tid, n, h);
                 h++;
                 if (m >= LELEMS) continue;
                 if (LEAFLEN(m) != bits) LEAFLEN(m) = (uint8_t)bits;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
         HEAP(bn) = (1u << 16) | (uint32_t)node;
         opt_len--;
     }
-    const int bniter = merge_loop(tm.heap, tid, bn, BLELEMS);
+    const int bniter = merge_loop<HT>(tm.heap, tid, bn, BLELEMS);
     for (int i = 0; i < 16; i++) BLCOUNT(i) = 0;
     overflow = 0;
     for (int it = bniter - 1; it >= 0; it--) {
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ s
         for (int bits = 7; bits != 0; bits--) {
             int cnt = BLCOUNT(bits);
             while (cnt != 0) {
-                const int m = removed_node(tm.heap, tid, bn, h);
+                const int m = removed_node<HT>(tm.heap, tid, bn, h);
                 h++;
                 if (m >= BLELEMS) continue;
                 if ((int)BLLEN(m) != bits) BLLEN(m) = (uint32_t)bits;

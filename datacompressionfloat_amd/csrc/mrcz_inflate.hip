@@ -11,7 +11,7 @@
  *   (mrcz_inflate_par.hip)  the block-parallel decoder proper: candidate scan, speculative block decode, chain, gather
  *   k_inflate        sequential general decoder (any distance), one wave per stream; only runs for streams the
  *                    parallel kernels hand over (matches with distance != 1, or malformed input)
- *   k_merge_planes   4 byte planes -> float words (uint4 stores)
+ *   (k_merge_segments, mrcz_inflate_par.hip)  4 byte planes -> float words
  */
 #include "mrcz_common.h"
 
@@ -251,58 +251,6 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ rec,
         if (final) break;
     }
     if (bad || op != d.n) atomicAdd((unsigned long long *)&result[1], 1ull);
-}
-
-/* four plane bytes of positions [i, i+4) of a stream: from its decoded plane buffer, or -- for a RAW
- * plane (zip.c:267-270) -- straight from the payload in the records (any byte alignment) */
-__device__ __forceinline__ uint32_t plane_word(const uint8_t *planes, const uint8_t *rec, const DecStream &d, uint32_t s, uint32_t i)
-{
-    if (!d.raw) return *reinterpret_cast<const uint32_t *>(planes + (size_t)s * CHK + i);
-    const uint8_t *p = rec + d.payoff + i;
-    const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
-    if (mis == 0) return *reinterpret_cast<const uint32_t *>(p);
-    if (i + 8u > d.n) /* the second aligned dword could end past the payload: bytes instead */
-        return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-    const uint32_t a = *reinterpret_cast<const uint32_t *>(p - mis), b = *reinterpret_cast<const uint32_t *>(p - mis + 4);
-    return (a >> (8u * mis)) | (b << (32u - 8u * mis));
-}
-
-/* merge_byte_to_float_stream (workers.c:423-442): byte j of word c*chk + i = plane j of chunk c at i */
-__global__ __launch_bounds__(256) void k_merge_planes(const uint8_t *__restrict__ planes, const uint8_t *__restrict__ rec,
-                                                      const DecStream *__restrict__ ds, uint64_t nfloats, uint32_t chk,
-                                                      uint32_t *__restrict__ out)
-{
-    const uint32_t c = blockIdx.y;
-    const uint64_t cbase = (uint64_t)c * chk;
-    const uint32_t n = (uint32_t)((nfloats - cbase) < chk ? (nfloats - cbase) : chk);
-    const DecStream d0 = ds[4 * c], d1 = ds[4 * c + 1], d2 = ds[4 * c + 2], d3 = ds[4 * c + 3];
-    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; 4ull * q < n; q += gridDim.x * 256) {
-        const uint32_t i = 4 * q;
-        if (i + 4 <= n) {
-            const uint32_t a = plane_word(planes, rec, d0, 4 * c, i), b = plane_word(planes, rec, d1, 4 * c + 1, i);
-            const uint32_t cc = plane_word(planes, rec, d2, 4 * c + 2, i), d = plane_word(planes, rec, d3, 4 * c + 3, i);
-            /* 4x4 byte transpose back */
-            const uint32_t ab_lo = __byte_perm(a, b, 0x5140), ab_hi = __byte_perm(a, b, 0x7362);
-            const uint32_t cd_lo = __byte_perm(cc, d, 0x5140), cd_hi = __byte_perm(cc, d, 0x7362);
-            uint4 v;
-            v.x = __byte_perm(ab_lo, cd_lo, 0x5410);
-            v.y = __byte_perm(ab_lo, cd_lo, 0x7632);
-            v.z = __byte_perm(ab_hi, cd_hi, 0x5410);
-            v.w = __byte_perm(ab_hi, cd_hi, 0x7632);
-            if (((cbase + i) & 3ull) == 0) *reinterpret_cast<uint4 *>(out + cbase + i) = v;
-            else { out[cbase + i] = v.x; out[cbase + i + 1] = v.y; out[cbase + i + 2] = v.z; out[cbase + i + 3] = v.w; }
-        } else {
-            for (uint32_t k = i; k < n; k++) {
-                uint32_t w = 0;
-                for (int j = 0; j < 4; j++) {
-                    const DecStream &dj = j == 0 ? d0 : j == 1 ? d1 : j == 2 ? d2 : d3;
-                    const uint8_t *src = dj.raw ? rec + dj.payoff : planes + (size_t)(4 * c + j) * CHK;
-                    w |= (uint32_t)src[k] << (8 * j);
-                }
-                out[cbase + k] = w;
-            }
-        }
-    }
 }
 
 /* apply_mask alone (erasebytes restatement, src/tool/erasebytes.c:109-134) */

@@ -1053,12 +1053,6 @@ struct Cand {
     uint32_t nwin;   /* windows decoded */
     uint32_t lead;   /* leading bytes that replicate the previous block's last byte */
 };
-struct BlkJob {
-    uint32_t stream, bit, off, inlast;
-    uint32_t slot;     /* stream * MAXCAND + candidate slot; 0xffffffff = stored block */
-    uint32_t src, len; /* stored block: payload byte offset and length of its data */
-    uint32_t pad;
-};
 
 
 /* D1: every bit position of every compressed payload is tested for the signature of a dynamic-block
@@ -1360,77 +1354,147 @@ __global__ __launch_bounds__(256) void k_cand_index(const uint32_t *__restrict__
     candbase[nstreams] = run;
 }
 
-/* D2: decode every candidate block without writing: where does it end, how many plane bytes does it
- * produce, what is its last byte */
+/* D2: decode every candidate block as if it were real: where does it end, how many plane bytes does it produce, what is
+ * its last byte; the bytes wait in the scratch buffer.  The grid is FIXED (a few workgroups per CU) and the workgroups
+ * pull candidate numbers from a device counter until it passes the total that k_cand_index left in candbase[nstreams]:
+ * the host never needs to know how many candidates the scan found, so nothing is read back between the decode stages. */
 __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_blk_count(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                   const DecStream *__restrict__ ds, uint32_t nstreams,
                                                   const uint32_t *__restrict__ candbase, Cand *__restrict__ cands,
                                                   uint8_t *__restrict__ scratch, uint32_t *__restrict__ scratch_top, uint32_t scratch_cap16,
-                                                  HdrCache *__restrict__ hdrs, uint32_t calltag, unsigned long long *__restrict__ dbg)
+                                                  HdrCache *__restrict__ hdrs, uint32_t calltag, uint32_t *__restrict__ jobctr,
+                                                  unsigned long long *__restrict__ dbg)
 {
-    /* one workgroup per candidate block: decode it as if it were real, leave its bytes in the scratch buffer, record
-     * where it ends and how much it produced; k_chain then keeps the candidates that form the stream's chain */
     HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
     ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
     const int tid = threadIdx.x;
-    const uint32_t job = blockIdx.x;
-    uint32_t lo = 0, hi = nstreams - 1;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (candbase[mid] <= job) lo = mid; else hi = mid - 1;
-    }
-    const uint32_t s = lo, ci = job - candbase[lo];
-    Cand *c = &cands[(size_t)s * MAXCAND + ci];
-    const DecStream d = ds[s];
-    const StreamView sv = make_view(rec, reclen, d, nullptr);
-    if (tid == 0) { sh.cur = c->bit; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
-    if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
-    __syncthreads();
-    ScratchOut so;
-    so.base = scratch; so.top = scratch_top; so.cap16 = scratch_cap16; so.wbase = c->wbase; so.wlen = c->wlen;
-    decode_one_block<MODE_SCRATCH>(sh, sv, tid, dbg, so, hdrs + ((size_t)s * MAXCAND + ci), hdr_tag(calltag, c->bit));
-    __syncthreads();
-    if (tid == 0) {
-        const bool ok = (sh.status == 0 || sh.status == 1) && sh.cur > c->bit;
-        c->end = sh.cur;
-        c->nout = sh.op;
-        c->nwin = sh.nwin;
-        c->lead = sh.haslit ? sh.lead : sh.op; /* no literal at all: the whole block repeats the previous byte */
-        if (dbg) for (int i = 0; i < 20; i++) atomicAdd(&dbg[(size_t)s * 20 + i], sh.acc[i]);
-        c->info = (ok ? 1u : 0u) | 2u | (sh.haslit ? ((0x100u | (sh.last & 0xffu)) << 8) : 0u) | (sh.status == 1 ? 4u : 0u);
+    const uint32_t total = candbase[nstreams];
+    for (;;) {
+        if (tid == 0) sh.flag = atomicAdd(jobctr, 1u);
+        __syncthreads();
+        const uint32_t job = sh.flag;
+        __syncthreads(); /* everybody has read the job number before sh.flag is reused */
+        if (job >= total) break; /* uniform: every wave leaves in the same iteration */
+        uint32_t lo = 0, hi = nstreams - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (candbase[mid] <= job) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t s = lo, ci = job - candbase[lo];
+        Cand *c = &cands[(size_t)s * MAXCAND + ci];
+        const DecStream d = ds[s];
+        const StreamView sv = make_view(rec, reclen, d, nullptr);
+        if (tid == 0) { sh.cur = c->bit; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
+        if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
+        __syncthreads();
+        ScratchOut so;
+        so.base = scratch; so.top = scratch_top; so.cap16 = scratch_cap16; so.wbase = c->wbase; so.wlen = c->wlen;
+        decode_one_block<MODE_SCRATCH>(sh, sv, tid, dbg, so, hdrs + ((size_t)s * MAXCAND + ci), hdr_tag(calltag, c->bit));
+        __syncthreads();
+        if (tid == 0) {
+            const bool ok = (sh.status == 0 || sh.status == 1) && sh.cur > c->bit;
+            c->end = sh.cur;
+            c->nout = sh.op;
+            c->nwin = sh.nwin;
+            c->lead = sh.haslit ? sh.lead : sh.op; /* no literal at all: the whole block repeats the previous byte */
+            if (dbg) for (int i = 0; i < 20; i++) atomicAdd(&dbg[(size_t)s * 20 + i], sh.acc[i]);
+            c->info = (ok ? 1u : 0u) | 2u | (sh.haslit ? ((0x100u | (sh.last & 0xffu)) << 8) : 0u) | (sh.status == 1 ? 4u : 0u);
+        }
+        __syncthreads();
     }
 }
 
+/* Where the plane bytes of a stream are once the chains are closed: a stream is a sorted, gap-free list of SEGMENTS,
+ * each a run of plane bytes that sits contiguously somewhere -- a decoded window in the scratch buffer, the data of a
+ * stored block or a whole RAW plane in the records, or (streams the sequential decoders had to take) the plane buffer.
+ * k_merge_segments reads the four planes of a tile straight from their segments, so the decoded blocks are never
+ * copied to a plane buffer first (that copy was 1.65 GB of traffic per GiB of floats). */
+constexpr int MAXSEG = 2048;            /* segments per stream; a stream that needs more is decoded sequentially */
+constexpr int MTILE = 4096;             /* plane positions per merge tile */
+constexpr int MTILES = CHK / MTILE;     /* 1536 */
+constexpr uint64_t SEG_REC = 1ull << 62, SEG_PLANES = 1ull << 63, SEG_OFFMASK = (1ull << 62) - 1ull;
+struct Seg {
+    uint64_t src;        /* byte offset inside the scratch buffer; | SEG_REC: inside the records; | SEG_PLANES: inside the plane buffer */
+    uint32_t dst, len;   /* plane positions [dst, dst + len) */
+    uint32_t fill_until; /* positions below this one (leading repeats of a block) take fillb instead of the source byte */
+    uint32_t fillb;
+};
+constexpr uint32_t CH_SLOTS = 2048, CH_EMPTY = 0xffffffffu; /* hash of candidate start bits: <= MAXCAND keys */
+constexpr uint32_t CH_STORED = 0xffffu;                      /* block list entry: a stored block (no candidate) */
+
+/* D3: per stream, follow the chain of blocks from bit 0 (a candidate is accepted only where the previous block ended,
+ * stored blocks are sized on the spot) and lay the accepted blocks' windows out as segments; segidx[t] = the segment
+ * that holds the first position of merge tile t.  One wave per stream, two phases:
+ *   1. the walk itself, strictly serial but in LDS only: candidate start bits in a hash, the fields a step depends on
+ *      (end, bytes, info) in LDS arrays, so one step is two LDS round trips; it leaves the list of accepted blocks;
+ *   2. the blocks' windows -> segments, one block per lane (the window records come from global memory, 64 independent
+ *      loads at a time), segment numbers by a wave prefix sum. */
 __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, uint64_t reclen,
                                               const DecStream *__restrict__ ds, const Cand *__restrict__ cands,
-                                              const uint32_t *__restrict__ ncand, const uint32_t *__restrict__ candbase,
-                                              BlkJob *__restrict__ jobs, BlkJob *__restrict__ jobs_tmp,
-                                              uint32_t *__restrict__ njobs, uint32_t *__restrict__ fallback)
+                                              const uint32_t *__restrict__ ncand, Seg *__restrict__ segs,
+                                              uint32_t *__restrict__ nseg, uint16_t *__restrict__ segidx,
+                                              uint32_t *__restrict__ fallback, uint32_t force_fallback)
 {
+    __shared__ uint32_t h_key[CH_SLOTS];
+    __shared__ uint16_t h_val[CH_SLOTS];
+    __shared__ uint32_t c_end[MAXCAND], c_nout[MAXCAND], c_info[MAXCAND];
+    __shared__ uint32_t b_off[MAXCAND], b_src[MAXCAND], b_nout[MAXCAND]; /* accepted blocks, in stream order */
+    __shared__ uint16_t b_idx[MAXCAND];
+    __shared__ uint8_t b_last[MAXCAND];
     const uint32_t s = blockIdx.x;
     const DecStream d = ds[s];
     const int lane = lane_id();
-    if (d.raw) { if (lane == 0) fallback[s] = 0; return; }
+    Seg *sg = segs + (size_t)s * MAXSEG;
+    uint16_t *ix = segidx + (size_t)s * MTILES;
+    const uint32_t ntile = (d.n + MTILE - 1) / MTILE;
+    /* the whole stream as ONE segment (RAW planes; streams left to the sequential decoders) */
+    auto single = [&](uint64_t src) {
+        if (lane == 0) {
+            Seg g;
+            g.src = src; g.dst = 0; g.len = d.n; g.fill_until = 0; g.fillb = 0;
+            sg[0] = g;
+            nseg[s] = d.n ? 1u : 0u;
+        }
+        for (uint32_t t = (uint32_t)lane; t < ntile; t += 64u) ix[t] = 0;
+    };
+    if (d.raw) { single(SEG_REC | d.payoff); if (lane == 0) fallback[s] = 0; return; }
+    if (force_fallback || d.n == 0) { single(SEG_PLANES | ((uint64_t)s * CHK)); if (lane == 0) fallback[s] = d.n ? 1u : 0u; return; }
     uint32_t nc = ncand[s];
     bool fail = nc > (uint32_t)MAXCAND;
     if (nc > (uint32_t)MAXCAND) nc = MAXCAND;
     const Cand *cs = cands + (size_t)s * MAXCAND;
-    uint32_t pos = 0, off = 0, last = 0, nj = 0;
-    BlkJob *mine = jobs_tmp + (size_t)s * MAXCAND; /* the chain's jobs are collected here, then appended to the job list
-                                                    * with ONE reservation (a returning atomic per block on one counter
-                                                    * serialises all streams in L2) */
-    for (uint32_t step = 0; !fail && off < d.n && step < (uint32_t)MAXCAND; step++) {
-        /* the candidate that starts exactly at pos */
-        uint32_t found = 0xffffffffu;
-        for (uint32_t i0 = 0; i0 < nc; i0 += 64) {
-            const uint32_t i = i0 + (uint32_t)lane;
-            const bool m = i < nc && cs[i].bit == pos && (cs[i].info & 1u);
-            const unsigned long long b = __ballot(m);
-            if (b) { found = i0 + (uint32_t)__builtin_ctzll(b); break; }
+    for (uint32_t i = (uint32_t)lane; i < CH_SLOTS; i += 64u) h_key[i] = CH_EMPTY;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = (uint32_t)lane; i < nc; i += 64u) {
+        const Cand c = cs[i];
+        c_end[i] = c.end; c_nout[i] = c.nout; c_info[i] = c.info;
+        if (c.info & 1u) {
+            uint32_t slot = (c.bit * 2654435761u) >> 21;
+            for (;;) {
+                const uint32_t prev = atomicCAS(&h_key[slot], CH_EMPTY, c.bit);
+                if (prev == CH_EMPTY) { h_val[slot] = (uint16_t)i; break; }
+                if (prev == c.bit) break; /* the same start bit twice: the first one stands */
+                slot = (slot + 1u) & (CH_SLOTS - 1u);
+            }
         }
-        Cand c;
-        uint32_t stored_src = 0;
-        if (found == 0xffffffffu) {
+    }
+    __builtin_amdgcn_wave_barrier();
+    /* ---- phase 1: the walk (uniform: every lane probes the same slots) ---- */
+    uint32_t pos = 0, off = 0, last = 0, nblk = 0;
+    while (!fail && off < d.n) {
+        if (nblk >= (uint32_t)MAXCAND) { fail = true; break; }
+        uint32_t found = CH_STORED;
+        {
+            uint32_t slot = (pos * 2654435761u) >> 21;
+            for (uint32_t probes = 0; probes < CH_SLOTS; probes++) {
+                const uint32_t k = h_key[slot];
+                if (k == pos) { found = h_val[slot]; break; }
+                if (k == CH_EMPTY) break;
+                slot = (slot + 1u) & (CH_SLOTS - 1u);
+            }
+        }
+        uint32_t cend, cnout, cinfo, stored_src = 0;
+        if (found == CH_STORED) {
             /* no dynamic-header candidate here: zlib stores incompressible blocks (typically the first and
              * the last block of a near-random plane); a stored block is sized from its LEN field directly */
             const uint64_t g0 = d.payoff * 8ull + pos;
@@ -1439,90 +1503,68 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
             if ((uint64_t)db + 32u > (uint64_t)d.paylen * 8u) { fail = true; break; }
             const uint32_t l = gbits(rec, reclen, d.payoff * 8ull + db, 16), nl = gbits(rec, reclen, d.payoff * 8ull + db + 16, 16);
             if ((l ^ 0xffffu) != nl || (uint64_t)db + 32u + 8ull * l > (uint64_t)d.paylen * 8u) { fail = true; break; }
-            c.bit = pos; c.end = db + 32u + 8u * l; c.nout = l;
-            stored_src = (db >> 3) + 4u;
-            c.info = 3u | (l ? ((0x100u | (uint32_t)rec[d.payoff + (db >> 3) + 4u + l - 1u]) << 8) : 0u);
-            if (l == 0u && off < d.n && c.end >= d.paylen * 8u) { fail = true; break; } /* only the sync marker is left */
-        } else c = cs[found];
-        if (off + c.nout > d.n || c.end <= pos) { fail = true; break; }
-        if (lane == 0) {
-            BlkJob b;
-            b.stream = s; b.bit = pos; b.off = off; b.inlast = last;
-            b.slot = found == 0xffffffffu ? 0xffffffffu : s * (uint32_t)MAXCAND + found;
-            b.src = stored_src; b.len = c.nout; b.pad = 0;
-            mine[nj] = b;
-        }
-        nj++;
-        off += c.nout;
-        if (c.info >> 8) last = (c.info >> 8) & 0xffu;
-        pos = c.end;
-        if ((c.info & 4u) && off < d.n) { fail = true; break; } /* a final block before the plane is complete */
+            cend = db + 32u + 8u * l; cnout = l;
+            stored_src = (db >> 3) + 4u; /* payload byte where the block's data starts */
+            cinfo = 3u | (l ? ((0x100u | (uint32_t)rec[d.payoff + stored_src + l - 1u]) << 8) : 0u);
+            if (l == 0u && off < d.n && cend >= d.paylen * 8u) { fail = true; break; } /* only the sync marker is left */
+        } else { cend = c_end[found]; cnout = c_nout[found]; cinfo = c_info[found]; }
+        if (off + cnout > d.n || cend <= pos) { fail = true; break; }
+        if (lane == 0) { b_idx[nblk] = (uint16_t)found; b_off[nblk] = off; b_src[nblk] = stored_src; b_nout[nblk] = cnout; b_last[nblk] = (uint8_t)last; }
+        nblk++;
+        off += cnout;
+        if (cinfo >> 8) last = (cinfo >> 8) & 0xffu;
+        pos = cend;
+        if ((cinfo & 4u) && off < d.n) { fail = true; break; } /* a final block before the plane is complete */
     }
     if (!fail && off != d.n) fail = true;
-    if (lane == 0) fallback[s] = fail ? 1u : 0u; /* a failed stream is decoded by k_inflate_par instead */
-    if (!fail && nj) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(njobs, nj);
-        base = (uint32_t)__shfl((int)base, 0);
-        __builtin_amdgcn_wave_barrier(); /* lane 0's records are visible to the wave (same wave, in-order memory) */
-        for (uint32_t i = (uint32_t)lane; i < nj; i += 64u) jobs[base + i] = mine[i];
-    }
-}
-
-/* D4: decode the accepted blocks again, this time writing plane bytes at their final offsets */
-/* byte copy with arbitrary source and destination alignment, shared by `parts` workgroups (this one is `part`):
- * 16 bytes per lane and step (gfx9 global memory takes unaligned accesses), bytes for the tail.  The first `lead`
- * bytes of the destination receive `fillb` instead of the source. */
-__device__ __forceinline__ void wg_copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lead, uint32_t fillb, int tid, uint32_t part,
-                                        uint32_t parts)
-{
-    const uint32_t nq = n >> 4;
-    const uint32_t fw = 0x01010101u * (fillb & 0xffu);
-#pragma unroll 2
-    for (uint32_t i = part * 256u + (uint32_t)tid; i < nq; i += 256u * parts) {
-        uint4 w;
-        __builtin_memcpy(&w, src + 16u * i, 16);
-        if (16u * i < lead) {
-            if (16u * i + 16u <= lead) w = make_uint4(fw, fw, fw, fw);
-            else {
-                uint8_t b[16];
-                __builtin_memcpy(b, &w, 16);
+    __builtin_amdgcn_wave_barrier();
+    /* ---- phase 2: one block per lane -> its segments ---- */
+    uint32_t nsg = 0;
+    for (uint32_t j0 = 0; !fail && j0 < nblk; j0 += 64u) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        uint32_t wl[CAND_WINDOWS], wb[CAND_WINDOWS], nlive = 0, lead = 0, boff = 0, bl = 0, nout = 0;
+        bool bad = false, stored = false;
 #pragma unroll
-                for (uint32_t k = 0; k < 16u; k++) if (16u * i + k < lead) b[k] = (uint8_t)fillb;
-                __builtin_memcpy(&w, b, 16);
+        for (int w = 0; w < CAND_WINDOWS; w++) { wl[w] = 0; wb[w] = 0; }
+        if (j < nblk) {
+            boff = b_off[j]; nout = b_nout[j]; bl = b_last[j];
+            if (b_idx[j] == CH_STORED) { stored = true; wl[0] = nout; wb[0] = b_src[j]; nlive = nout ? 1u : 0u; }
+            else {
+                const Cand &c = cs[b_idx[j]];
+                const uint32_t nw = c.nwin;
+                lead = c.lead < nout ? c.lead : nout;
+                uint32_t sum = 0;
+                if (nw > (uint32_t)CAND_WINDOWS) bad = true;
+                else {
+#pragma unroll
+                    for (int w = 0; w < CAND_WINDOWS; w++)
+                        if ((uint32_t)w < nw) { wl[w] = c.wlen[w]; wb[w] = c.wbase[w]; sum += wl[w]; nlive += wl[w] ? 1u : 0u; }
+                }
+                if (sum != nout) bad = true; /* windows and block size disagree: not a block this path decoded */
             }
         }
-        __builtin_memcpy(dst + 16u * i, &w, 16);
+        uint32_t tot;
+        const uint32_t pre = wave_excl_sum(nlive, &tot);
+        if (__ballot(bad) != 0ull || nsg + tot > (uint32_t)MAXSEG) { fail = true; break; }
+        uint32_t k = nsg + pre, p = boff;
+#pragma unroll
+        for (int w = 0; w < CAND_WINDOWS; w++) {
+            const uint32_t l = wl[w];
+            if (l == 0u) continue;
+            Seg g;
+            g.src = stored ? (SEG_REC | (d.payoff + wb[w])) : (uint64_t)wb[w] * 16ull;
+            g.dst = p; g.len = l; g.fill_until = boff + lead; g.fillb = bl;
+            sg[k] = g;
+            /* tiles whose first position lies in this segment (a window holds a few; the megabyte-long windows of an
+             * all-zero plane are one or two per stream) */
+            for (uint32_t t = (p + MTILE - 1u) / MTILE; t * MTILE < p + l; t++) ix[t] = (uint16_t)k;
+            k++;
+            p += l;
+        }
+        nsg += tot;
     }
-    if (part == 0)
-        for (uint32_t i = 16u * nq + (uint32_t)tid; i < n; i += 256u) dst[i] = i < lead ? (uint8_t)fillb : src[i];
-}
-
-/* GATHER_PARTS workgroups per block of a closed chain: move the block's bytes to their place in the plane (a block
- * of an all-zero plane is megabytes long, a literal block 32 KiB: several workgroups share the long ones) */
-constexpr uint32_t GATHER_PARTS = 4;
-__global__ __launch_bounds__(256) void k_blk_gather(const uint8_t *__restrict__ rec, const DecStream *__restrict__ ds,
-                                                    const BlkJob *__restrict__ jobs, const Cand *__restrict__ cands,
-                                                    const uint32_t *__restrict__ fallback, const uint8_t *__restrict__ scratch,
-                                                    uint8_t *__restrict__ planes)
-{
-    const BlkJob job = jobs[blockIdx.x];
-    if (fallback[job.stream]) return;
-    const int tid = threadIdx.x;
-    const uint32_t part = blockIdx.y;
-    uint8_t *dst = planes + (size_t)job.stream * CHK + job.off;
-    if (job.slot == 0xffffffffu) { /* stored block: its bytes sit in the records */
-        wg_copy(dst, rec + ds[job.stream].payoff + job.src, job.len, 0u, 0u, tid, part, GATHER_PARTS);
-        return;
-    }
-    const Cand &c = cands[job.slot];
-    const uint32_t lead = c.lead < c.nout ? c.lead : c.nout; /* bytes that repeat the previous block's last byte */
-    uint32_t acc = 0;
-    for (uint32_t w = 0; w < c.nwin && w < (uint32_t)CAND_WINDOWS; w++) {
-        const uint32_t len = c.wlen[w];
-        wg_copy(dst + acc, scratch + (size_t)c.wbase[w] * 16u, len, lead > acc ? lead - acc : 0u, job.inlast, tid, part, GATHER_PARTS);
-        acc += len;
-    }
+    if (fail) { single(SEG_PLANES | ((uint64_t)s * CHK)); if (lane == 0) fallback[s] = 1u; return; } /* k_inflate_par decodes it into the plane buffer */
+    if (lane == 0) { nseg[s] = nsg; fallback[s] = 0u; }
 }
 
 __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ rec, uint64_t reclen,
@@ -1559,6 +1601,106 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
         if (dbg) for (int i = 0; i < 20; i++) dbg[(size_t)s * 20 + i] = sh.acc[i];
     }
 }
+/* D5: merge_byte_to_float_stream (workers.c:423-442): byte j of word c * chk + i = plane j of chunk c at position i.
+ * One workgroup per tile of MTILE positions, wave w gathers plane w of the tile from its segments into LDS (16
+ * destination-aligned bytes per lane and step, read at whatever alignment the source has -- gfx9 global memory takes
+ * unaligned 16-byte loads), then every thread transposes 4 x 4 bytes and stores one uint4 of floats. */
+__global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ scratch,
+                                                        const uint8_t *__restrict__ planes, const Seg *__restrict__ segs,
+                                                        const uint32_t *__restrict__ nseg, const uint16_t *__restrict__ segidx,
+                                                        uint64_t nfloats, uint32_t chk, uint32_t *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) uint4 tile[4][MTILE / 16];
+    const uint32_t c = blockIdx.y;
+    const uint64_t cbase = (uint64_t)c * chk;
+    const uint32_t n = (uint32_t)((nfloats - cbase) < chk ? (nfloats - cbase) : chk);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t s = 4u * c + (uint32_t)w;
+    const Seg *sg = segs + (size_t)s * MAXSEG;
+    const uint32_t ns = nseg[s];
+    auto base_of = [&](uint64_t src) -> const uint8_t * {
+        return ((src & SEG_REC) ? rec : (src & SEG_PLANES) ? planes : scratch) + (src & SEG_OFFMASK);
+    };
+    /* bytes [p, p + 16) of the plane through the segment list, starting the search at segment k (any alignment, any
+     * number of segments, end of the chunk): the general path */
+    auto slow16 = [&](uint32_t p, uint32_t pend, uint32_t k) -> uint4 {
+        uint8_t b[16];
+        Seg cur = sg[k];
+#pragma unroll 1
+        for (uint32_t q = 0; q < 16u; q++) {
+            const uint32_t pp = p + q;
+            uint8_t x = 0;
+            if (pp < pend) {
+                while (pp >= cur.dst + cur.len && k + 1u < ns) { k++; cur = sg[k]; }
+                if (pp >= cur.dst && pp < cur.dst + cur.len) x = pp < cur.fill_until ? (uint8_t)cur.fillb : base_of(cur.src)[pp - cur.dst];
+            }
+            b[q] = x;
+        }
+        uint4 v;
+        __builtin_memcpy(&v, b, 16);
+        return v;
+    };
+    auto fast16 = [&](const Seg &g, uint32_t p) -> uint4 {
+        uint4 v;
+        __builtin_memcpy(&v, base_of(g.src) + (p - g.dst), 16);
+        if (p < g.fill_until) { /* leading repeats of a block: the previous block's last byte */
+            uint8_t b[16];
+            __builtin_memcpy(b, &v, 16);
+#pragma unroll
+            for (uint32_t q = 0; q < 16u; q++) if (p + q < g.fill_until) b[q] = (uint8_t)g.fillb;
+            __builtin_memcpy(&v, b, 16);
+        }
+        return v;
+    };
+    for (uint32_t t = blockIdx.x; (uint64_t)t * MTILE < n; t += gridDim.x) {
+        const uint32_t p0 = t * MTILE, pend = (n - p0) < (uint32_t)MTILE ? n : p0 + MTILE;
+        /* nearly every tile lies in one segment or two: both are fetched with wave-uniform loads */
+        const uint32_t k0 = ns ? segidx[(size_t)s * MTILES + t] : 0u;
+        Seg A, B;
+        A.src = 0; A.dst = 0; A.len = 0; A.fill_until = 0; A.fillb = 0;
+        B = A;
+        if (k0 < ns) A = sg[k0];
+        if (k0 + 1u < ns) B = sg[k0 + 1u];
+        const uint32_t aend = A.dst + A.len, bend = B.dst + B.len;
+#pragma unroll
+        for (int j = 0; j < MTILE / 16 / 64; j++) {
+            const uint32_t g = (uint32_t)lane + 64u * (uint32_t)j, p = p0 + 16u * g;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p < pend && ns) { /* a stream without segments (malformed container): zeros, never a stale descriptor */
+                if (p + 16u <= pend && p >= A.dst && p + 16u <= aend) v = fast16(A, p);
+                else if (p + 16u <= pend && p >= B.dst && p + 16u <= bend) v = fast16(B, p);
+                else v = slow16(p, pend, k0);
+            }
+            tile[w][g] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MTILE / 4 / 256; j++) {
+            const uint32_t q = threadIdx.x + 256u * (uint32_t)j, i = p0 + 4u * q;
+            if (i >= n) continue;
+            const uint32_t a = reinterpret_cast<const uint32_t *>(tile[0])[q], b = reinterpret_cast<const uint32_t *>(tile[1])[q];
+            const uint32_t cc = reinterpret_cast<const uint32_t *>(tile[2])[q], dd = reinterpret_cast<const uint32_t *>(tile[3])[q];
+            /* 4x4 byte transpose back */
+            const uint32_t ab_lo = __byte_perm(a, b, 0x5140), ab_hi = __byte_perm(a, b, 0x7362);
+            const uint32_t cd_lo = __byte_perm(cc, dd, 0x5140), cd_hi = __byte_perm(cc, dd, 0x7362);
+            uint4 v;
+            v.x = __byte_perm(ab_lo, cd_lo, 0x5410);
+            v.y = __byte_perm(ab_lo, cd_lo, 0x7632);
+            v.z = __byte_perm(ab_hi, cd_hi, 0x5410);
+            v.w = __byte_perm(ab_hi, cd_hi, 0x7632);
+            uint32_t *o = out + cbase + i;
+            if (i + 4u <= n && (((uintptr_t)o) & 15u) == 0) *reinterpret_cast<uint4 *>(o) = v;
+            else {
+                o[0] = v.x;
+                if (i + 1u < n) o[1] = v.y;
+                if (i + 2u < n) o[2] = v.z;
+                if (i + 3u < n) o[3] = v.w;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 #undef PHASE
 
 } /* namespace mrcz */

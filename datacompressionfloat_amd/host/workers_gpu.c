@@ -28,6 +28,38 @@ static void die(const char *what, mrcz_ctx_t *c)
     exit(-1);
 }
 
+/* print_result (src/core/zip.c:401-466, compiled in by _PRINT_ZIPS_, src/include/constant.h:31): the per-plane table
+ * run_compress / run_uncompress print before they return (workers.c:863-865, 675-677).  fsz[j] / zfsz[j] are what the
+ * reference accumulates in mzip_t.fsz / .zfsz of byte stream j. */
+static void print_result_table(const uint64_t fsz[4], const uint64_t zfsz[4], double zipTime, double unzipTime, const char *hintMsg)
+{
+    const char *c1 = "[ByteStreamIndex]   ", *c2 = "[Before Compress(Bytes)]   ", *c3 = "[After Compress(Bytes)]   ", *c4 = "[Compress Ratio]   ";
+    uint64_t f = 0, z = 0;
+    printf("-------------------%s Information--------------\n", hintMsg);
+    printf("%s%s%s%s\n", c1, c2, c3, c4);
+    for (int i = 0; i < COMPRESSION_PATH_NUM; i++) {
+        f += fsz[i];
+        z += zfsz[i];
+        printf("%-*d%-*ld%-*ld%-*.*f\n", (int)strlen(c1), i, (int)strlen(c2), (long)fsz[i], (int)strlen(c3), (long)zfsz[i], (int)strlen(c4), 4,
+               (double)zfsz[i] / (double)fsz[i]);
+    }
+    printf("%-*s", (int)strlen(c1), "Whole File");
+    printf("%-*ld%-*ld%-*.*f\n", (int)strlen(c2), (long)f, (int)strlen(c3), (long)z, (int)strlen(c4), 4, (double)z / (double)f);
+    if (zipTime > 0.001) {
+        printf("---------------------------------------\n");
+        printf("%s Overall: zipTime = %f, original file size = %ld, compressed file size = %ld, file reduced = %.4f%s\n", hintMsg, zipTime,
+               (long)f, (long)z, (1.0 - (double)z / (double)f) * 100.0, "%");
+        printf("---------------------------------------\n");
+        printf("Compression Throughputs: %f MB/s\n", (double)f / (1024.0 * 1024.0 * zipTime));
+        printf("---------------------------------------\n");
+    }
+    if (unzipTime > 0.001) {
+        printf("---------------------------------------\n");
+        printf("Decompression Throughput: %f MB/s\n", (double)f / (1024.0 * 1024.0 * unzipTime));
+        printf("---------------------------------------\n");
+    }
+}
+
 /* ---- per-thread session: codec context + pinned / device staging buffers, kept between calls ----
  * The reference's worker threads call run_compress / run_uncompress once per file (adapt.c:28-90).  Creating a
  * context and pinning a gigabyte of host memory costs far more than coding a file, so a thread keeps its session

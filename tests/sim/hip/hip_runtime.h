@@ -114,6 +114,7 @@ template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v
 template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <typename T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
+template <typename T> static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 
@@ -138,6 +139,8 @@ static inline const char *hipGetErrorString(hipError_t) { return "sim"; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 1; return hipSuccess; }
 double sim_now();
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(sizeof(**e)); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU): A/B the host-side scheduling knobs of the codec on the 1 GiB b=8 volume in ONE process.
+The knobs are environment variables read by mrcz_create (MRCZ_LANES, MRCZ_STAGGER, MRCZ_HT, MRCZ_BLK_GRID, ...)."""
+import itertools
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from datacompressionfloat_amd import MrcZipCodec
+
+dev = torch.device("cuda", 0)
+n = int(float(os.environ.get("TUNE_GIB", "1")) * (1 << 28))
+bits = int(os.environ.get("TUNE_BITS", "8"))
+g = torch.Generator(device=dev).manual_seed(1234)
+words = torch.empty(n, dtype=torch.float32, device=dev).normal_(10.0, 3.0, generator=g).view(torch.int32)
+words[:256] = 0
+nchunks = (n + 6291455) // 6291456
+
+
+def timed(fn, reps=8):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, r
+
+
+def run(env):
+    for k in list(os.environ):
+        if k.startswith("MRCZ_"):
+            del os.environ[k]
+    os.environ.update({k: str(v) for k, v in env.items()})
+    codec = MrcZipCodec(0, max_batch_chunks=min(128, nchunks))
+    rec_buf = torch.empty(codec.records_bound(n), dtype=torch.uint8, device=dev)
+    out_buf = torch.empty(n, dtype=torch.int32, device=dev)
+    tc, (rec, _) = timed(lambda: codec.compress_device(words, bits, 0, out=rec_buf))
+    td, (out, _) = timed(lambda: codec.uncompress_device(rec, n, out=out_buf))
+    exp = words.clone()
+    codec.erase_bits_device(exp, bits, 0)
+    ok = bool(torch.equal(out, exp))
+    codec.close()
+    return {"env": env, "compress_ms": round(tc * 1e3, 3), "decompress_ms": round(td * 1e3, 3), "compress_GBps": round(4.0 * n / tc / 1e9, 1),
+            "decompress_GBps": round(4.0 * n / td / 1e9, 1), "roundtrip_ok": ok}
+
+
+which = sys.argv[1] if len(sys.argv) > 1 else "compress"
+res = []
+if which == "compress":
+    for lanes, stagger, ht in [(2, 0, 48), (2, 1, 48), (3, 1, 48), (4, 1, 48), (2, 1, 16), (3, 1, 16), (4, 1, 16), (4, 1, 32), (4, 0, 16), (1, 0, 48)]:
+        res.append(run({"MRCZ_LANES": lanes, "MRCZ_STAGGER": stagger, "MRCZ_HT": ht}))
+        print(json.dumps(res[-1]), flush=True)
+elif which == "decompress":
+    for grid in (512, 768, 1024, 1536, 3072):
+        res.append(run({"MRCZ_BLK_GRID": grid}))
+        print(json.dumps(res[-1]), flush=True)
+else:
+    env = dict(kv.split("=") for kv in sys.argv[1:])
+    print(json.dumps(run(env)), flush=True)
