@@ -28,6 +28,7 @@ struct mrcz_ctx {
     uint32_t max_chunks;
     uint32_t row_chunks;           /* chunk rows of the workspace (>= max_chunks, a multiple of the lane count) */
     hipStream_t stream;            /* everything except ...                                                     */
+    hipStream_t up_stream, down_stream; /* host -> device and device -> host copies of the asynchronous API */
     hipStream_t lane_stream[MAX_LANES]; /* ... the lanes of a compress batch (see mrcz_compress_chunks); [0] = stream */
     hipEvent_t ev_start, ev_cont, ev_done[MAX_LANES];
     hipEvent_t ev_stream[MAX_LANES]; /* lane l's summary + histogram passes are done */
@@ -135,6 +136,8 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->row_chunks = ctx->lanes * ((max_batch_chunks + ctx->lanes - 1u) / ctx->lanes);
     const size_t ns = 4u * (size_t)ctx->row_chunks;
     for (int l = 1; l < MAX_LANES && e == hipSuccess; l++) e = hipStreamCreate(&ctx->lane_stream[l]);
+    if (e == hipSuccess) e = hipStreamCreate(&ctx->up_stream);
+    if (e == hipSuccess) e = hipStreamCreate(&ctx->down_stream);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_cont, hipEventDisableTiming);
     for (int l = 0; l < MAX_LANES && e == hipSuccess; l++) e = hipEventCreateWithFlags(&ctx->ev_done[l], hipEventDisableTiming);
@@ -208,6 +211,8 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
         if (ctx->ev_done[l]) (void)hipEventDestroy(ctx->ev_done[l]);
         if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
     }
+    if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
+    if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -336,15 +341,16 @@ static int compress_lane(mrcz_ctx *ctx, hipStream_t lstream, int phase, int slot
     return MRCZ_OK;
 }
 
-extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk, int bits,
-                                    void *d_out, uint64_t out_cap, uint64_t *out_len, uint64_t plane_bytes[4])
+/* enqueue a compress call on the context's compute stream(s); its five result words (bytes written, per-plane sums) are copied
+ * to the pinned host words h_res[0..4] in stream order.  No host synchronisation. */
+static int compress_enqueue(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk, int bits, void *d_out, uint64_t out_cap,
+                            uint64_t *h_res)
 {
-    if (!ctx || !d_in || !d_out || !out_len) return MRCZ_EINVAL;
+    if (!ctx || !d_in || !d_out || !h_res) return MRCZ_EINVAL;
     if (bits < 0 || bits > 32) return fail(ctx, MRCZ_EINVAL, "bits outside 0..32 (reference table has 33 entries, workers.c:29-37)", hipSuccess);
     if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 3u)) return fail(ctx, MRCZ_EINVAL, "d_in must be 16-byte and d_out 4-byte aligned", hipSuccess);
-    *out_len = 0;
     ctx->ntimers = 0;
-    if (nfloats == 0) return MRCZ_OK;
+    if (nfloats == 0) return fail(ctx, MRCZ_EINVAL, "nothing to compress", hipSuccess);
     const uint64_t bound = mrcz_records_bound(nfloats);
     if (out_cap < bound) return fail(ctx, MRCZ_ECAP, "output capacity below mrcz_records_bound()", hipSuccess);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
@@ -417,7 +423,17 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
         HIPCHK(hipEventRecord(ctx->ev_done[l], ctx->lane_stream[l]), "event");
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_done[l], 0), "wait");
     }
-    HIPCHK(hipMemcpyAsync(ctx->h_result, ctx->result, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
+    HIPCHK(hipMemcpyAsync(h_res, ctx->result, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
+    return MRCZ_OK;
+}
+
+extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk, int bits,
+                                    void *d_out, uint64_t out_cap, uint64_t *out_len, uint64_t plane_bytes[4])
+{
+    if (!ctx || !out_len) return MRCZ_EINVAL;
+    *out_len = 0;
+    if (nfloats == 0) { ctx->ntimers = 0; return (d_in && d_out) ? MRCZ_OK : MRCZ_EINVAL; }
+    if (int rc = compress_enqueue(ctx, d_in, nfloats, first_chunk, bits, d_out, out_cap, ctx->h_result)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (compress)");
     *out_len = ctx->h_result[0];
     if (plane_bytes)
@@ -425,13 +441,19 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
     return MRCZ_OK;
 }
 
-extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
-                                      void *d_out, uint64_t *consumed)
+extern "C" int mrcz_compress_chunks_async(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk, int bits,
+                                          void *d_out, uint64_t out_cap, uint64_t *h_result5)
 {
-    if (!ctx || !d_out) return MRCZ_EINVAL;
-    if (consumed) *consumed = 0;
+    return compress_enqueue(ctx, d_in, nfloats, first_chunk, bits, d_out, out_cap, h_result5);
+}
+
+/* enqueue an uncompress call; its three result words (record bytes consumed, error count, streams handed to the sequential
+ * decoder) are copied to the pinned host words h_res[0..2] in stream order.  No host synchronisation. */
+static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk, void *d_out, uint64_t *h_res)
+{
+    if (!ctx || !d_out || !h_res) return MRCZ_EINVAL;
     ctx->ntimers = 0;
-    if (nfloats == 0) return MRCZ_OK;
+    if (nfloats == 0) return fail(ctx, MRCZ_EINVAL, "nothing to uncompress", hipSuccess);
     if (!d_records) return MRCZ_EINVAL;
     if (chk == 0 || chk > CHK) return fail(ctx, MRCZ_EFORMAT, "chunk size in header exceeds CHUNK_SIZE (constant.h:25)", hipSuccess);
     if (((uintptr_t)d_out & 15u) || ((uintptr_t)d_records & 3u)) return fail(ctx, MRCZ_EINVAL, "d_out must be 16-byte and d_records 4-byte aligned", hipSuccess);
@@ -478,11 +500,86 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
         LAUNCH("k_merge_segments", k_merge_segments, dim3(512, nb), dim3(256), rec, ctx->scratch, ctx->planes, ctx->segs, ctx->nseg, ctx->segidx, bfl,
                chk, out + c0 * chk);
     }
-    HIPCHK(hipMemcpyAsync(ctx->h_result, ctx->result, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
+    HIPCHK(hipMemcpyAsync(h_res, ctx->result, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
+    return MRCZ_OK;
+}
+
+extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
+                                      void *d_out, uint64_t *consumed)
+{
+    if (!ctx || !d_out) return MRCZ_EINVAL;
+    if (consumed) *consumed = 0;
+    if (nfloats == 0) { ctx->ntimers = 0; return MRCZ_OK; }
+    if (int rc = uncompress_enqueue(ctx, d_records, len, nfloats, chk, d_out, ctx->h_result)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (uncompress)");
     if (consumed) *consumed = ctx->h_result[0];
     ctx->last_fallbacks = ctx->h_result[2];
     if (ctx->h_result[1]) return fail(ctx, MRCZ_EFORMAT, "malformed chunk records or deflate stream", hipSuccess);
+    return MRCZ_OK;
+}
+
+extern "C" int mrcz_uncompress_chunks_async(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
+                                            void *d_out, uint64_t *h_result3)
+{
+    return uncompress_enqueue(ctx, d_records, len, nfloats, chk, d_out, h_result3);
+}
+
+/* ---- events and the three streams of a context (pipelines: include/mrcz_hip.h) ---- */
+struct mrcz_event { hipEvent_t ev; };
+static hipStream_t stream_of(mrcz_ctx *ctx, int id) { return id == MRCZ_STREAM_UPLOAD ? ctx->up_stream : id == MRCZ_STREAM_DOWNLOAD ? ctx->down_stream : ctx->stream; }
+
+extern "C" int mrcz_event_create(mrcz_ctx_t *ctx, mrcz_event_t **ev)
+{
+    if (!ctx || !ev) return MRCZ_EINVAL;
+    *ev = NULL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    mrcz_event *e = (mrcz_event *)calloc(1, sizeof(mrcz_event));
+    if (!e) return MRCZ_ENOMEM;
+    hipError_t r = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+    if (r != hipSuccess) { free(e); return fail(ctx, MRCZ_EHIP, "hipEventCreate", r); }
+    *ev = e;
+    return MRCZ_OK;
+}
+extern "C" void mrcz_event_destroy(mrcz_ctx_t *ctx, mrcz_event_t *ev)
+{
+    if (!ev) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipEventDestroy(ev->ev);
+    free(ev);
+}
+extern "C" int mrcz_event_record(mrcz_ctx_t *ctx, int stream_id, mrcz_event_t *ev)
+{
+    if (!ctx || !ev) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipEventRecord(ev->ev, stream_of(ctx, stream_id)), "hipEventRecord");
+    return MRCZ_OK;
+}
+extern "C" int mrcz_stream_wait_event(mrcz_ctx_t *ctx, int stream_id, mrcz_event_t *ev)
+{
+    if (!ctx || !ev) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipStreamWaitEvent(stream_of(ctx, stream_id), ev->ev, 0), "hipStreamWaitEvent");
+    return MRCZ_OK;
+}
+extern "C" int mrcz_event_sync(mrcz_ctx_t *ctx, mrcz_event_t *ev)
+{
+    if (!ctx || !ev) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipEventSynchronize(ev->ev), "hipEventSynchronize");
+    return MRCZ_OK;
+}
+extern "C" int mrcz_copy_h2d_async(mrcz_ctx_t *ctx, int stream_id, void *d_dst, const void *h_src, uint64_t bytes)
+{
+    if (!ctx) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, stream_of(ctx, stream_id)), "copy h2d");
+    return MRCZ_OK;
+}
+extern "C" int mrcz_copy_d2h_async(mrcz_ctx_t *ctx, int stream_id, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    if (!ctx) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, stream_of(ctx, stream_id)), "copy d2h");
     return MRCZ_OK;
 }
 

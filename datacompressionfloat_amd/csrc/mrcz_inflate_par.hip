@@ -1605,6 +1605,30 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
  * One workgroup per tile of MTILE positions, wave w gathers plane w of the tile from its segments into LDS (16
  * destination-aligned bytes per lane and step, read at whatever alignment the source has -- gfx9 global memory takes
  * unaligned 16-byte loads), then every thread transposes 4 x 4 bytes and stores one uint4 of floats. */
+struct SegBases { const uint8_t *rec, *scratch, *planes; };
+__device__ __forceinline__ const uint8_t *seg_base(const SegBases &sb, uint64_t src)
+{
+    return ((src & SEG_REC) ? sb.rec : (src & SEG_PLANES) ? sb.planes : sb.scratch) + (src & SEG_OFFMASK);
+}
+/* bytes [p, p + 16) of a plane through its segment list, starting the search at segment k (any alignment, any number of
+ * segments, end of the chunk): the general path of the merge, a handful of lanes per tile at most */
+__device__ __noinline__ uint4 merge_slow16(const SegBases sb, const Seg *__restrict__ sg, uint32_t ns, uint32_t p, uint32_t pend, uint32_t k)
+{
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    uint32_t cdst = sg[k].dst, clen = sg[k].len;
+    for (uint32_t q = 0; q < 16u; q++) {
+        const uint32_t pp = p + q;
+        uint32_t x = 0;
+        if (pp < pend) {
+            while (pp >= cdst + clen && k + 1u < ns) { k++; cdst = sg[k].dst; clen = sg[k].len; }
+            if (pp >= cdst && pp < cdst + clen) x = pp < sg[k].fill_until ? (sg[k].fillb & 0xffu) : (uint32_t)seg_base(sb, sg[k].src)[pp - cdst];
+        }
+        const uint32_t sh = x << (8u * (q & 3u));
+        if (q < 4u) w0 |= sh; else if (q < 8u) w1 |= sh; else if (q < 12u) w2 |= sh; else w3 |= sh;
+    }
+    return make_uint4(w0, w1, w2, w3);
+}
+
 __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ scratch,
                                                         const uint8_t *__restrict__ planes, const Seg *__restrict__ segs,
                                                         const uint32_t *__restrict__ nseg, const uint16_t *__restrict__ segidx,
@@ -1615,63 +1639,51 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
     const uint64_t cbase = (uint64_t)c * chk;
     const uint32_t n = (uint32_t)((nfloats - cbase) < chk ? (nfloats - cbase) : chk);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t s = 4u * c + (uint32_t)w;
+    const uint32_t s = 4u * c + (uint32_t)__builtin_amdgcn_readfirstlane(w);
     const Seg *sg = segs + (size_t)s * MAXSEG;
     const uint32_t ns = nseg[s];
-    auto base_of = [&](uint64_t src) -> const uint8_t * {
-        return ((src & SEG_REC) ? rec : (src & SEG_PLANES) ? planes : scratch) + (src & SEG_OFFMASK);
-    };
-    /* bytes [p, p + 16) of the plane through the segment list, starting the search at segment k (any alignment, any
-     * number of segments, end of the chunk): the general path */
-    auto slow16 = [&](uint32_t p, uint32_t pend, uint32_t k) -> uint4 {
-        uint8_t b[16];
-        Seg cur = sg[k];
-#pragma unroll 1
-        for (uint32_t q = 0; q < 16u; q++) {
-            const uint32_t pp = p + q;
-            uint8_t x = 0;
-            if (pp < pend) {
-                while (pp >= cur.dst + cur.len && k + 1u < ns) { k++; cur = sg[k]; }
-                if (pp >= cur.dst && pp < cur.dst + cur.len) x = pp < cur.fill_until ? (uint8_t)cur.fillb : base_of(cur.src)[pp - cur.dst];
-            }
-            b[q] = x;
-        }
-        uint4 v;
-        __builtin_memcpy(&v, b, 16);
-        return v;
-    };
-    auto fast16 = [&](const Seg &g, uint32_t p) -> uint4 {
-        uint4 v;
-        __builtin_memcpy(&v, base_of(g.src) + (p - g.dst), 16);
-        if (p < g.fill_until) { /* leading repeats of a block: the previous block's last byte */
-            uint8_t b[16];
-            __builtin_memcpy(b, &v, 16);
-#pragma unroll
-            for (uint32_t q = 0; q < 16u; q++) if (p + q < g.fill_until) b[q] = (uint8_t)g.fillb;
-            __builtin_memcpy(&v, b, 16);
-        }
-        return v;
-    };
+    SegBases sb;
+    sb.rec = rec; sb.scratch = scratch; sb.planes = planes;
     for (uint32_t t = blockIdx.x; (uint64_t)t * MTILE < n; t += gridDim.x) {
         const uint32_t p0 = t * MTILE, pend = (n - p0) < (uint32_t)MTILE ? n : p0 + MTILE;
-        /* nearly every tile lies in one segment or two: both are fetched with wave-uniform loads */
-        const uint32_t k0 = ns ? segidx[(size_t)s * MTILES + t] : 0u;
+        /* nearly every tile lies in one segment or two: both are fetched with wave-uniform (scalar) loads */
+        const uint32_t k0 = ns ? (uint32_t)__builtin_amdgcn_readfirstlane((int)segidx[(size_t)s * MTILES + t]) : 0u;
         Seg A, B;
         A.src = 0; A.dst = 0; A.len = 0; A.fill_until = 0; A.fillb = 0;
         B = A;
         if (k0 < ns) A = sg[k0];
         if (k0 + 1u < ns) B = sg[k0 + 1u];
+        const uint8_t *abase = seg_base(sb, A.src), *bbase = seg_base(sb, B.src);
         const uint32_t aend = A.dst + A.len, bend = B.dst + B.len;
+        /* four independent 16-byte loads per lane first (destination-aligned groups, source at any alignment), patches after */
+        uint4 v[MTILE / 16 / 64];
+        bool ok[MTILE / 16 / 64];
 #pragma unroll
         for (int j = 0; j < MTILE / 16 / 64; j++) {
             const uint32_t g = (uint32_t)lane + 64u * (uint32_t)j, p = p0 + 16u * g;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (p < pend && ns) { /* a stream without segments (malformed container): zeros, never a stale descriptor */
-                if (p + 16u <= pend && p >= A.dst && p + 16u <= aend) v = fast16(A, p);
-                else if (p + 16u <= pend && p >= B.dst && p + 16u <= bend) v = fast16(B, p);
-                else v = slow16(p, pend, k0);
-            }
-            tile[w][g] = v;
+            const bool inA = p >= A.dst && p + 16u <= aend, inB = p >= B.dst && p + 16u <= bend;
+            ok[j] = ns != 0u && p + 16u <= pend && (inA || inB);
+            const uint8_t *src = inA ? abase + (p - A.dst) : bbase + (p - B.dst);
+            v[j] = make_uint4(0, 0, 0, 0);
+            if (ok[j]) __builtin_memcpy(&v[j], src, 16);
+        }
+#pragma unroll
+        for (int j = 0; j < MTILE / 16 / 64; j++) {
+            const uint32_t g = (uint32_t)lane + 64u * (uint32_t)j, p = p0 + 16u * g;
+            if (ok[j]) {
+                const bool inA = p >= A.dst && p + 16u <= aend;
+                const uint32_t fu = inA ? A.fill_until : B.fill_until;
+                if (p < fu) { /* leading repeats of a block: the previous block's last byte */
+                    const uint32_t nf = fu - p, fw = 0x01010101u * ((inA ? A.fillb : B.fillb) & 0xffu);
+                    uint32_t *vw = reinterpret_cast<uint32_t *>(&v[j]);
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; k++) {
+                        const uint32_t m = nf >= 4u * (k + 1u) ? 0xffffffffu : (nf <= 4u * k ? 0u : ((1u << (8u * (nf - 4u * k))) - 1u));
+                        vw[k] = (vw[k] & ~m) | (fw & m);
+                    }
+                }
+            } else if (p < pend && ns) v[j] = merge_slow16(sb, sg, ns, p, pend, k0); /* (a stream without segments -- malformed container -- stays zero) */
+            tile[w][g] = v[j];
         }
         __syncthreads();
 #pragma unroll
@@ -1683,18 +1695,18 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
             /* 4x4 byte transpose back */
             const uint32_t ab_lo = __byte_perm(a, b, 0x5140), ab_hi = __byte_perm(a, b, 0x7362);
             const uint32_t cd_lo = __byte_perm(cc, dd, 0x5140), cd_hi = __byte_perm(cc, dd, 0x7362);
-            uint4 v;
-            v.x = __byte_perm(ab_lo, cd_lo, 0x5410);
-            v.y = __byte_perm(ab_lo, cd_lo, 0x7632);
-            v.z = __byte_perm(ab_hi, cd_hi, 0x5410);
-            v.w = __byte_perm(ab_hi, cd_hi, 0x7632);
+            uint4 o4;
+            o4.x = __byte_perm(ab_lo, cd_lo, 0x5410);
+            o4.y = __byte_perm(ab_lo, cd_lo, 0x7632);
+            o4.z = __byte_perm(ab_hi, cd_hi, 0x5410);
+            o4.w = __byte_perm(ab_hi, cd_hi, 0x7632);
             uint32_t *o = out + cbase + i;
-            if (i + 4u <= n && (((uintptr_t)o) & 15u) == 0) *reinterpret_cast<uint4 *>(o) = v;
+            if (i + 4u <= n && (((uintptr_t)o) & 15u) == 0) *reinterpret_cast<uint4 *>(o) = o4;
             else {
-                o[0] = v.x;
-                if (i + 1u < n) o[1] = v.y;
-                if (i + 2u < n) o[2] = v.z;
-                if (i + 3u < n) o[3] = v.w;
+                o[0] = o4.x;
+                if (i + 1u < n) o[1] = o4.y;
+                if (i + 2u < n) o[2] = o4.z;
+                if (i + 3u < n) o[3] = o4.w;
             }
         }
         __syncthreads();

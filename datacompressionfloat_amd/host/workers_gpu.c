@@ -1,12 +1,24 @@
 /*
  * workers_gpu.c -- run_compress / run_uncompress of the reference
  * (/root/reference/src/core/workers.c:690-881 and :568-688, declared in src/include/workers.h:30-31)
- * re-implemented as the "chunk scheduler" of the MI355X codec: the file is read in batches of
- * chunks into pinned host memory by a reader thread while the previous batch is on the GPU
- * (H2D, include/mrcz_hip.h kernels, D2H), and the chunk records are written in order.  Same
- * signatures, same container bytes, same ctx side effects; errors that the reference answers
- * with exit(-1) (workers.c:708-712) do the same here.  There is no CPU codec in this file: if the
- * HIP library cannot create a context the call fails loudly.
+ * re-implemented as the "chunk scheduler" of the MI355X codec.  The reference handles one chunk at a
+ * time (fread -> mask/split -> 4 x deflate -> fwrite, workers.c:779-855); here a file flows through a
+ * three-stage pipeline whose stages all run at once:
+ *
+ *   reader thread   fread one chunk into a pinned ring slot, enqueue its host->device copy (upload stream)
+ *   caller thread   when the chunks of a batch are on their way, enqueue the codec kernels (compute stream)
+ *   writer thread   device->host copy of the batch's result in slices (download stream), fwrite in order
+ *
+ * with two device batch buffers per direction, so batch k+1 is uploaded and batch k-1 downloaded while
+ * batch k is coded.  Ordering is done with the events of include/mrcz_hip.h; the host only blocks on the
+ * event it needs next.  All worker threads of a process share ONE codec context per GPU (the reference's
+ * N worker threads each call run_compress, src/main/mrc_tarx.c:134-176): the enqueue of a batch is a few
+ * microseconds under a mutex, the batches of different files are then coded one after the other on the
+ * compute stream while every thread's own copies and file I/O overlap them.
+ *
+ * Same signatures, same container bytes, same ctx side effects, same summary table (print_result,
+ * src/core/zip.c:401-466); errors that the reference answers with exit(-1) (workers.c:708-712) do the
+ * same here.  There is no CPU codec in this file: without a usable HIP device the call fails loudly.
  */
 #include "../../include/mrcz_hip.h"
 #include "../../include/mrcz_workers.h"
@@ -16,17 +28,25 @@
 
 int isTestThroughput = 0; /* src/core/workers.c:39 */
 
+#define MAXDEV 16
+#define R_IN 4                    /* pinned input ring: chunk-sized slots */
+#define R_OUT 3                   /* pinned output ring */
+#define OUT_SLOT (32u << 20)      /* bytes per output slice */
+#define CHUNK_BYTES ((uint64_t)CHUNK_SIZE * 4u)
+#define IN_SLOT (CHUNK_BYTES + 64u) /* a chunk of floats, or a chunk record (16-byte header + <= 4 RAW planes) */
+
 static __thread int t_device = 0;
-static __thread int t_batch_chunks = 8; /* 192 MiB of floats per batch: pinning host memory costs ~0.2 s per GiB */
+static int g_batch_chunks = 8; /* chunks per device batch: 192 MiB of floats */
 
 void mrcz_workers_set_device(int device) { t_device = device; }
-void mrcz_workers_set_batch_chunks(int chunks) { t_batch_chunks = chunks < 1 ? 1 : (chunks > 128 ? 128 : chunks); }
+void mrcz_workers_set_batch_chunks(int chunks) { g_batch_chunks = chunks < 1 ? 1 : (chunks > 128 ? 128 : chunks); }
 
 static void die(const char *what, mrcz_ctx_t *c)
 {
     fprintf(stderr, "[%s:%d] ERROR: %s: %s\n", __FILE__, __LINE__, what, c ? mrcz_last_error(c) : "");
     exit(-1);
 }
+#define CK(call, what, c) do { if ((call) != MRCZ_OK) die(what, c); } while (0)
 
 /* print_result (src/core/zip.c:401-466, compiled in by _PRINT_ZIPS_, src/include/constant.h:31): the per-plane table
  * run_compress / run_uncompress print before they return (workers.c:863-865, 675-677).  fsz[j] / zfsz[j] are what the
@@ -60,18 +80,42 @@ static void print_result_table(const uint64_t fsz[4], const uint64_t zfsz[4], do
     }
 }
 
-/* ---- per-thread session: codec context + pinned / device staging buffers, kept between calls ----
- * The reference's worker threads call run_compress / run_uncompress once per file (adapt.c:28-90).  Creating a
- * context and pinning a gigabyte of host memory costs far more than coding a file, so a thread keeps its session
- * until it exits (or its device / batch size changes). */
+/* ---- one codec context per GPU, shared by every thread of the process ---- */
 typedef struct {
     mrcz_ctx_t *c;
-    int device, batch;
-    void *h_fl[2]; /* pinned: up to batch floats each (the second one only once a file needs a second batch) */
-    void *h_rec;   /* pinned: records of a batch */
-    void *d_fl;    /* device: batch floats */
-    void *d_rec;   /* device: records of a batch */
-    uint64_t h_fl_cap[2], h_rec_cap, d_fl_cap, d_rec_cap; /* bytes; buffers grow to what the files so far needed */
+    int batch;
+    pthread_mutex_t mu; /* held while a batch is enqueued on the compute stream */
+} engine_t;
+static engine_t g_eng[MAXDEV];
+static pthread_mutex_t g_eng_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static engine_t *engine_get(int device)
+{
+    if (device < 0 || device >= MAXDEV) die("device index out of range", NULL);
+    engine_t *e = &g_eng[device];
+    pthread_mutex_lock(&g_eng_mu);
+    if (!e->c) {
+        if (mrcz_create(&e->c, device, (uint32_t)g_batch_chunks) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
+        e->batch = g_batch_chunks;
+        pthread_mutex_init(&e->mu, NULL);
+    }
+    pthread_mutex_unlock(&g_eng_mu);
+    return e;
+}
+
+/* ---- per-thread session: pinned rings, device batch buffers, events; kept between calls ----
+ * The reference's worker threads call run_compress / run_uncompress once per file (adapt.c:28-90); pinning host
+ * memory costs ~0.2 s per GiB, so a thread keeps its (small, chunk-granular) rings until it exits. */
+typedef struct {
+    engine_t *e;
+    int device;
+    void *h_in[R_IN], *h_out[R_OUT];
+    uint64_t *h_res[2];              /* pinned result words of the two batches in flight */
+    void *d_a[2], *d_b[2];           /* device: batch input [2], batch output [2] */
+    uint64_t d_a_cap, d_b_cap;
+    mrcz_event_t *in_ev[R_IN];       /* upload of ring slot i is done */
+    mrcz_event_t *out_ev[R_OUT];     /* download into ring slot i is done */
+    mrcz_event_t *up_ev[2], *comp_ev[2], *down_ev[2]; /* batch buffer b: uploaded / coded / downloaded */
 } session_t;
 static __thread session_t t_s;
 static pthread_key_t s_key;
@@ -80,46 +124,259 @@ static pthread_once_t s_once = PTHREAD_ONCE_INIT;
 static void session_release(void *p)
 {
     session_t *s = (session_t *)p;
-    if (!s || !s->c) return;
-    mrcz_host_free(s->c, s->h_fl[0]); mrcz_host_free(s->c, s->h_fl[1]); mrcz_host_free(s->c, s->h_rec);
-    mrcz_dev_free(s->c, s->d_fl); mrcz_dev_free(s->c, s->d_rec);
-    mrcz_destroy(s->c);
+    if (!s || !s->e) return;
+    mrcz_ctx_t *c = s->e->c;
+    for (int i = 0; i < R_IN; i++) { if (s->h_in[i]) mrcz_host_free(c, s->h_in[i]); mrcz_event_destroy(c, s->in_ev[i]); }
+    for (int i = 0; i < R_OUT; i++) { if (s->h_out[i]) mrcz_host_free(c, s->h_out[i]); mrcz_event_destroy(c, s->out_ev[i]); }
+    for (int b = 0; b < 2; b++) {
+        mrcz_host_free(c, s->h_res[b]);
+        mrcz_dev_free(c, s->d_a[b]); mrcz_dev_free(c, s->d_b[b]);
+        mrcz_event_destroy(c, s->up_ev[b]); mrcz_event_destroy(c, s->comp_ev[b]); mrcz_event_destroy(c, s->down_ev[b]);
+    }
     memset(s, 0, sizeof(*s));
 }
 static void session_key_init(void) { pthread_key_create(&s_key, session_release); }
 
-static session_t *session_get(void)
+/* rings and events once; device batch buffers sized for `a_bytes` in, `b_bytes` out (they only grow) */
+static session_t *session_get(uint64_t a_bytes, uint64_t b_bytes)
 {
     pthread_once(&s_once, session_key_init);
-    if (t_s.c && (t_s.device != t_device || t_s.batch != t_batch_chunks)) session_release(&t_s);
-    if (!t_s.c) {
-        if (mrcz_create(&t_s.c, t_device, (uint32_t)t_batch_chunks) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
-        t_s.device = t_device;
-        t_s.batch = t_batch_chunks;
-        pthread_setspecific(s_key, &t_s); /* released when the thread exits */
+    session_t *s = &t_s;
+    if (s->e && s->device != t_device) session_release(s);
+    if (!s->e) {
+        s->e = engine_get(t_device);
+        s->device = t_device;
+        mrcz_ctx_t *c = s->e->c;
+        /* the ring slots themselves are pinned on first use (reader: h_in, writer: h_out): a small file touches one of each */
+        for (int i = 0; i < R_IN; i++) CK(mrcz_event_create(c, &s->in_ev[i]), "event", c);
+        for (int i = 0; i < R_OUT; i++) CK(mrcz_event_create(c, &s->out_ev[i]), "event", c);
+        for (int b = 0; b < 2; b++) {
+            CK(mrcz_host_malloc(c, (void **)&s->h_res[b], 64), "fail to alloc mem", c);
+            CK(mrcz_event_create(c, &s->up_ev[b]), "event", c);
+            CK(mrcz_event_create(c, &s->comp_ev[b]), "event", c);
+            CK(mrcz_event_create(c, &s->down_ev[b]), "event", c);
+        }
+        pthread_setspecific(s_key, s); /* released when the thread exits */
     }
-    return &t_s;
-}
-/* make a staging buffer at least `need` bytes large (never shrinks) */
-static void session_grow(session_t *s, void **p, uint64_t *cap, uint64_t need, int host)
-{
-    if (*cap >= need && *p) return;
-    if (*p) { if (host) mrcz_host_free(s->c, *p); else mrcz_dev_free(s->c, *p); *p = NULL; *cap = 0; }
-    if ((host ? mrcz_host_malloc(s->c, p, need) : mrcz_dev_malloc(s->c, p, need)) != MRCZ_OK) die("fail to alloc mem", s->c);
-    *cap = need;
+    mrcz_ctx_t *c = s->e->c;
+    if (s->d_a_cap < a_bytes) {
+        for (int b = 0; b < 2; b++) { if (s->d_a[b]) mrcz_dev_free(c, s->d_a[b]); CK(mrcz_dev_malloc(c, &s->d_a[b], a_bytes), "fail to alloc mem", c); }
+        s->d_a_cap = a_bytes;
+    }
+    if (s->d_b_cap < b_bytes) {
+        for (int b = 0; b < 2; b++) { if (s->d_b[b]) mrcz_dev_free(c, s->d_b[b]); CK(mrcz_dev_malloc(c, &s->d_b[b], b_bytes), "fail to alloc mem", c); }
+        s->d_b_cap = b_bytes;
+    }
+    return s;
 }
 
-/* ---- double-buffered reader: fread of batch k+1 overlaps the GPU work on batch k ---- */
+/* ---- the pipeline of one call ---- */
 typedef struct {
-    FILE *f;
-    void *buf;
-    size_t elem, want, got;
-} read_job_t;
-static void *read_thread(void *arg)
+    uint64_t units;       /* compress: floats of the batch; uncompress: floats the batch decodes to */
+    uint64_t in_bytes;    /* bytes uploaded for the batch */
+    uint64_t first_chunk; /* index in the file of the batch's first chunk */
+    int last;             /* no batch follows */
+} batch_t;
+
+typedef struct {
+    session_t *s;
+    mrcz_ctx_t *c;
+    FILE *fin, *fout;
+    int decode;           /* 0 = run_compress, 1 = run_uncompress */
+    int bits;
+    uint32_t chk;         /* floats per chunk */
+    uint64_t total_floats;/* decode: floats of the file */
+    int batch_chunks;
+    /* queues (one slot per batch buffer is enough: at most two batches are in flight) */
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    batch_t q_up[2], q_done[2];
+    uint64_t n_read;      /* batches the reader has handed over */
+    uint64_t n_enq;       /* batches whose kernels are enqueued (comp_ev recorded) */
+    uint64_t n_down;      /* batches fully downloaded / written (down_ev recorded) */
+    int reader_eof;
+    /* results */
+    uint64_t plane_z[4];  /* compress: per-plane payload + header bytes (mzip_t.zfsz); uncompress: per-plane payload bytes */
+    uint64_t zbytes;      /* uncompress: record bytes read */
+    uint64_t nbatches;
+    double gpu_time;      /* time the writer spent waiting for coded batches (what the reference counts as zip/unzip time) */
+} pipe_t;
+
+static void *reader_main(void *arg)
 {
-    read_job_t *j = (read_job_t *)arg;
-    j->got = fread(j->buf, j->elem, j->want, j->f);
+    pipe_t *p = (pipe_t *)arg;
+    session_t *s = p->s;
+    mrcz_ctx_t *c = p->c;
+    uint64_t chunk = 0, k = 0, done_floats = 0;
+    int eof = 0;
+    while (!eof) {
+        const int b = (int)(k & 1u);
+        /* batch buffer b is free once batch k-2 has been coded: wait until its kernels are at least enqueued, then let the
+         * upload stream wait for them on the device */
+        pthread_mutex_lock(&p->mu);
+        while (k >= 2 && p->n_enq < k - 1) pthread_cond_wait(&p->cv, &p->mu);
+        pthread_mutex_unlock(&p->mu);
+        if (k >= 2) CK(mrcz_stream_wait_event(c, MRCZ_STREAM_UPLOAD, s->comp_ev[b]), "stream wait", c);
+        batch_t bt;
+        memset(&bt, 0, sizeof(bt));
+        bt.first_chunk = chunk;
+        uint64_t off = 0; /* bytes of the batch uploaded so far */
+        for (int i = 0; i < p->batch_chunks && !eof; i++) {
+            const int slot = (int)(chunk % R_IN);
+            if (chunk >= R_IN) CK(mrcz_event_sync(c, s->in_ev[slot]), "event sync", c); /* the slot's previous upload is done */
+            if (!s->h_in[slot]) CK(mrcz_host_malloc(c, &s->h_in[slot], IN_SLOT), "fail to alloc mem", c);
+            unsigned char *h = (unsigned char *)s->h_in[slot];
+            uint64_t bytes = 0;
+            if (!p->decode) {
+                if (done_floats >= p->total_floats) { eof = 1; break; }
+                const uint64_t left = p->total_floats - done_floats;
+                const size_t want = left < CHUNK_SIZE ? (size_t)left : (size_t)CHUNK_SIZE;
+                const size_t n = fread(h, sizeof(uint32_t), want, p->fin); /* workers.c:744,854 */
+                if (n == 0) { eof = 1; break; }
+                bytes = (uint64_t)n * 4u;
+                bt.units += n;
+                done_floats += n;
+                if (n < want || done_floats >= p->total_floats) eof = 1;
+            } else {
+                /* one chunk record: the 16-byte header (workers.c:52-69, unpack_header zip.c:393-399), then the four payloads */
+                if (done_floats >= p->total_floats) { eof = 1; break; }
+                if (fread(h, 1, 16, p->fin) != 16) die("truncated container (chunk header)", NULL);
+                uint64_t pay = 0;
+                for (int j = 0; j < 4; j++) {
+                    const uint64_t l = (uint64_t)h[4 * j] | ((uint64_t)h[4 * j + 1] << 8) | ((uint64_t)h[4 * j + 2] << 16) | ((uint64_t)(h[4 * j + 3] & 0x7f) << 24);
+                    p->plane_z[j] += l;
+                    pay += l;
+                }
+                if (16 + pay > IN_SLOT || fread(h + 16, 1, (size_t)pay, p->fin) != pay) die("truncated container (payload)", NULL);
+                bytes = 16 + pay;
+                const uint64_t left = p->total_floats - done_floats;
+                const uint64_t nfl = left < p->chk ? left : p->chk;
+                bt.units += nfl;
+                done_floats += nfl;
+                p->zbytes += bytes;
+                if (done_floats >= p->total_floats) eof = 1;
+            }
+            CK(mrcz_copy_h2d_async(c, MRCZ_STREAM_UPLOAD, (char *)s->d_a[b] + off, h, bytes), "H2D copy", c);
+            CK(mrcz_event_record(c, MRCZ_STREAM_UPLOAD, s->in_ev[slot]), "event record", c);
+            off += bytes;
+            chunk++;
+        }
+        if (bt.units == 0) break;
+        bt.in_bytes = off;
+        bt.last = eof;
+        CK(mrcz_event_record(c, MRCZ_STREAM_UPLOAD, s->up_ev[b]), "event record", c);
+        pthread_mutex_lock(&p->mu);
+        p->q_up[b] = bt;
+        p->n_read = k + 1;
+        pthread_cond_broadcast(&p->cv);
+        pthread_mutex_unlock(&p->mu);
+        k++;
+    }
+    pthread_mutex_lock(&p->mu);
+    p->reader_eof = 1;
+    pthread_cond_broadcast(&p->cv);
+    pthread_mutex_unlock(&p->mu);
     return NULL;
+}
+
+static void *writer_main(void *arg)
+{
+    pipe_t *p = (pipe_t *)arg;
+    session_t *s = p->s;
+    mrcz_ctx_t *c = p->c;
+    uint64_t oslice = 0; /* output ring position */
+    for (uint64_t k = 0;; k++) {
+        const int b = (int)(k & 1u);
+        pthread_mutex_lock(&p->mu);
+        while (p->n_enq <= k && !(p->reader_eof && p->n_read <= k)) pthread_cond_wait(&p->cv, &p->mu);
+        const int have = p->n_enq > k;
+        const batch_t bt = p->q_done[b];
+        pthread_mutex_unlock(&p->mu);
+        if (!have) break;
+        const double t0 = now_sec();
+        CK(mrcz_event_sync(c, s->comp_ev[b]), "event sync", c);
+        p->gpu_time += now_sec() - t0;
+        uint64_t out_bytes;
+        if (!p->decode) {
+            out_bytes = s->h_res[b][0];
+            for (int j = 0; j < 4; j++) p->plane_z[j] += s->h_res[b][1 + j];
+        } else {
+            if (s->h_res[b][1] != 0 || s->h_res[b][0] != bt.in_bytes) die("uncompress: malformed chunk records or deflate stream", NULL);
+            out_bytes = bt.units * 4u;
+        }
+        if (isTestThroughput != 1) {
+            /* slices of the result through the pinned output ring: the copy of slice j+1 runs while slice j is written */
+            const uint64_t nsl = (out_bytes + OUT_SLOT - 1) / OUT_SLOT;
+            uint64_t issued = 0, written = 0;
+            while (written < nsl) {
+                while (issued < nsl && issued < written + R_OUT - 1) {
+                    const int os = (int)((oslice + issued) % R_OUT);
+                    if (!s->h_out[os]) CK(mrcz_host_malloc(c, &s->h_out[os], OUT_SLOT), "fail to alloc mem", c);
+                    const uint64_t o = issued * OUT_SLOT, l = (out_bytes - o) < OUT_SLOT ? (out_bytes - o) : OUT_SLOT;
+                    CK(mrcz_copy_d2h_async(c, MRCZ_STREAM_DOWNLOAD, s->h_out[os], (char *)s->d_b[b] + o, l), "D2H copy", c);
+                    CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->out_ev[os]), "event record", c);
+                    issued++;
+                    if (issued == nsl) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->down_ev[b]), "event record", c);
+                }
+                const int os = (int)((oslice + written) % R_OUT);
+                const uint64_t o = written * OUT_SLOT, l = (out_bytes - o) < OUT_SLOT ? (out_bytes - o) : OUT_SLOT;
+                CK(mrcz_event_sync(c, s->out_ev[os]), "event sync", c);
+                if (fwrite(s->h_out[os], 1, (size_t)l, p->fout) != l) die("fwrite", NULL); /* workers.c:837-850 / 627,668 */
+                written++;
+            }
+            oslice += nsl;
+            if (nsl == 0) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->down_ev[b]), "event record", c);
+        } else CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->down_ev[b]), "event record", c);
+        pthread_mutex_lock(&p->mu);
+        p->n_down = k + 1;
+        pthread_cond_broadcast(&p->cv);
+        pthread_mutex_unlock(&p->mu);
+        if (bt.last) break;
+    }
+    return NULL;
+}
+
+/* the caller's thread: enqueue the codec for every batch the reader hands over */
+static void run_pipeline(pipe_t *p)
+{
+    session_t *s = p->s;
+    mrcz_ctx_t *c = p->c;
+    pthread_mutex_init(&p->mu, NULL);
+    pthread_cond_init(&p->cv, NULL);
+    pthread_t rd, wr;
+    if (pthread_create(&rd, NULL, reader_main, p) != 0 || pthread_create(&wr, NULL, writer_main, p) != 0) die("pthread_create", NULL);
+    const uint64_t rec_cap = mrcz_records_bound((uint64_t)p->batch_chunks * CHUNK_SIZE) + 64;
+    for (uint64_t k = 0;; k++) {
+        const int b = (int)(k & 1u);
+        pthread_mutex_lock(&p->mu);
+        while (p->n_read <= k && !p->reader_eof) pthread_cond_wait(&p->cv, &p->mu);
+        const int have = p->n_read > k;
+        const batch_t bt = p->q_up[b];
+        /* output buffer b and result words b are free once batch k-2 has been downloaded */
+        while (have && k >= 2 && p->n_down < k - 1) pthread_cond_wait(&p->cv, &p->mu);
+        pthread_mutex_unlock(&p->mu);
+        if (!have) break;
+        pthread_mutex_lock(&s->e->mu);
+        CK(mrcz_stream_wait_event(c, MRCZ_STREAM_COMPUTE, s->up_ev[b]), "stream wait", c);
+        if (k >= 2) CK(mrcz_stream_wait_event(c, MRCZ_STREAM_COMPUTE, s->down_ev[b]), "stream wait", c);
+        if (!p->decode)
+            CK(mrcz_compress_chunks_async(c, s->d_a[b], bt.units, bt.first_chunk, p->bits, s->d_b[b], rec_cap, s->h_res[b]), "compress", c);
+        else
+            CK(mrcz_uncompress_chunks_async(c, s->d_a[b], bt.in_bytes, bt.units, p->chk, s->d_b[b], s->h_res[b]), "uncompress", c);
+        CK(mrcz_event_record(c, MRCZ_STREAM_COMPUTE, s->comp_ev[b]), "event record", c);
+        pthread_mutex_unlock(&s->e->mu);
+        pthread_mutex_lock(&p->mu);
+        p->q_done[b] = bt;
+        p->n_enq = k + 1;
+        pthread_cond_broadcast(&p->cv);
+        pthread_mutex_unlock(&p->mu);
+        p->nbatches++;
+        if (bt.last) break;
+    }
+    pthread_join(rd, NULL);
+    pthread_join(wr, NULL);
+    pthread_mutex_destroy(&p->mu);
+    pthread_cond_destroy(&p->cv);
 }
 
 int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const char *dataConvertedType)
@@ -134,59 +391,32 @@ int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const 
         fprintf(stderr, "[%s:%d] ERROR: bits to erase must be in 0..32 (table of 33 masks, workers.c:29-37)\n", __FILE__, __LINE__);
         exit(-1);
     }
-    double begin = now_sec();
-    session_t *ses = session_get();
-    mrcz_ctx_t *c = ses->c;
-    const uint64_t batch_floats = (uint64_t)ses->batch * CHUNK_SIZE;
-    /* staging sized by what this file needs: a small file does not pin a whole batch */
-    const uint64_t file_floats = (uint64_t)get_file_size(fin) / 4u;
-    const uint64_t stage_floats = file_floats < batch_floats ? (file_floats ? file_floats : 1) : batch_floats;
-    const uint64_t rec_cap = mrcz_records_bound(stage_floats) + 64;
-    session_grow(ses, &ses->h_fl[0], &ses->h_fl_cap[0], stage_floats * 4, 1);
-    if (file_floats >= batch_floats) session_grow(ses, &ses->h_fl[1], &ses->h_fl_cap[1], batch_floats * 4, 1); /* a next batch will be read */
-    session_grow(ses, &ses->h_rec, &ses->h_rec_cap, rec_cap, 1);
-    session_grow(ses, &ses->d_fl, &ses->d_fl_cap, stage_floats * 4, 0);
-    session_grow(ses, &ses->d_rec, &ses->d_rec_cap, rec_cap, 0);
-    void *h_in[2] = {ses->h_fl[0], ses->h_fl[1]}, *h_out = ses->h_rec, *d_in = ses->d_fl, *d_out = ses->d_rec;
+    const double begin = now_sec();
+    const uint64_t fsz = get_file_size(fin);
+    const uint64_t file_floats = fsz / 4u;
+    if (file_floats == 0) return 0; /* workers.c:757: nothing is written when the first read is empty */
+    int batch = g_batch_chunks;
+    const uint64_t file_chunks = (file_floats + CHUNK_SIZE - 1) / CHUNK_SIZE;
+    if ((uint64_t)batch > file_chunks) batch = (int)file_chunks; /* a small file does not allocate a whole batch */
+    session_t *ses = session_get((uint64_t)batch * CHUNK_BYTES, mrcz_records_bound((uint64_t)batch * CHUNK_SIZE) + 64);
+    if (batch > ses->e->batch) batch = ses->e->batch;
 
     mrczip_header_t hd;
     init_mrczip_header(&hd, 0);
-    hd.chk = CHUNK_SIZE;            /* workers.c:735 */
-    hd.fsz = get_file_size(fin);    /* workers.c:743: the true size, also when it is not a multiple of 4 */
-    ctx->zipTime += now_sec() - begin;
+    hd.chk = CHUNK_SIZE; /* workers.c:735 */
+    hd.fsz = fsz;        /* workers.c:743: the true size, also when it is not a multiple of 4 */
+    if (isTestThroughput != 1) write_mrczip_header(fout, &hd); /* workers.c:757-765 */
 
-    uint64_t plane_total[4] = {0, 0, 0, 0};
-    uint64_t first_chunk = 0;
-    int cur = 0;
-    read_job_t job = {fin, h_in[0], sizeof(uint32_t), (size_t)batch_floats, 0};
-    read_thread(&job); /* first batch, synchronously (workers.c:744) */
-    size_t num = job.got;
-    if (num > 0 && isTestThroughput != 1) write_mrczip_header(fout, &hd); /* workers.c:757-765 */
-    while (num > 0) {
-        /* start reading the next batch while this one is compressed */
-        pthread_t th;
-        read_job_t next = {fin, h_in[cur ^ 1], sizeof(uint32_t), (size_t)batch_floats, 0};
-        const int more = (num == (size_t)batch_floats);
-        if (more && pthread_create(&th, NULL, read_thread, &next) != 0) die("pthread_create", NULL);
-        begin = now_sec();
-        uint64_t out_len = 0, planes[4];
-        if (mrcz_copy_h2d(c, d_in, h_in[cur], (uint64_t)num * 4)) die("H2D copy", c);
-        if (mrcz_compress_chunks(c, d_in, (uint64_t)num, first_chunk, bitsToMask, d_out, rec_cap, &out_len, planes)) die("compress", c);
-        if (isTestThroughput != 1) {
-            if (mrcz_copy_d2h(c, h_out, d_out, out_len)) die("D2H copy", c);
-        }
-        ctx->zipTime += now_sec() - begin;
-        for (int j = 0; j < 4; j++) plane_total[j] += planes[j];
-        if (isTestThroughput != 1) fwrite(h_out, 1, (size_t)out_len, fout); /* workers.c:837-850 */
-        first_chunk += (num + CHUNK_SIZE - 1) / CHUNK_SIZE;
-        if (more) {
-            pthread_join(th, NULL);
-            num = next.got;
-            cur ^= 1;
-        } else num = 0;
-    }
-    /* workers.c:870-873: sum of the per-plane compressed sizes (each includes its 4-byte header) */
-    for (int j = 0; j < 4; j++) ctx->allZipFileSize += plane_total[j];
+    pipe_t p;
+    memset(&p, 0, sizeof(p));
+    p.s = ses; p.c = ses->e->c; p.fin = fin; p.fout = fout; p.decode = 0; p.bits = bitsToMask; p.chk = CHUNK_SIZE; p.total_floats = file_floats; p.batch_chunks = batch;
+    run_pipeline(&p);
+    const double elapsed = now_sec() - begin;
+    ctx->zipTime += elapsed;
+    /* workers.c:863-873: the per-plane table, then the sum of the per-plane compressed sizes (each includes its 4-byte header) */
+    uint64_t f4[4] = {file_floats, file_floats, file_floats, file_floats};
+    print_result_table(f4, p.plane_z, elapsed, 0.0, "Compression Summary Result");
+    for (int j = 0; j < 4; j++) ctx->allZipFileSize += p.plane_z[j];
     return 0;
 }
 
@@ -207,50 +437,26 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
         fprintf(stderr, "[%s:%d] ERROR: bad chunk size %u in header\n", __FILE__, __LINE__, hd->chk);
         exit(-1);
     }
-    double start = now_sec();
+    const double begin = now_sec();
     const uint64_t nfloats = hd->fsz / COMPRESSION_PATH_NUM; /* workers.c:577 */
+    if (nfloats == 0) return 0;
     const uint32_t chk = hd->chk;
-    session_t *ses = session_get();
-    mrcz_ctx_t *c = ses->c;
-    const uint64_t batch_floats = (uint64_t)ses->batch * chk;
-    const uint64_t stage_floats = nfloats < batch_floats ? (nfloats ? nfloats : 1) : batch_floats;
-    const uint64_t rec_cap = mrcz_records_bound((stage_floats + chk - 1) / chk * CHUNK_SIZE) + 64;
-    session_grow(ses, &ses->h_rec, &ses->h_rec_cap, rec_cap, 1);
-    session_grow(ses, &ses->h_fl[0], &ses->h_fl_cap[0], stage_floats * 4, 1);
-    session_grow(ses, &ses->d_rec, &ses->d_rec_cap, rec_cap, 0);
-    session_grow(ses, &ses->d_fl, &ses->d_fl_cap, stage_floats * 4, 0);
-    void *h_rec = ses->h_rec, *h_out = ses->h_fl[0], *d_rec = ses->d_rec, *d_out = ses->d_fl;
-    ctx->unzipTime += now_sec() - start;
+    int batch = g_batch_chunks;
+    const uint64_t file_chunks = (nfloats + chk - 1) / chk;
+    if ((uint64_t)batch > file_chunks) batch = (int)file_chunks;
+    session_t *ses = session_get(mrcz_records_bound((uint64_t)batch * CHUNK_SIZE) + 64, (uint64_t)batch * CHUNK_BYTES);
+    if (batch > ses->e->batch) batch = ses->e->batch;
 
-    uint64_t done = 0, zbytes = 0;
-    while (done < nfloats) {
-        const uint64_t nfl = (nfloats - done) < batch_floats ? (nfloats - done) : batch_floats;
-        const uint64_t nchunks = (nfl + chk - 1) / chk;
-        /* read the batch's records: walk the 16-byte chunk headers (workers.c:52-69) */
-        uint64_t len = 0;
-        for (uint64_t k = 0; k < nchunks; k++) {
-            unsigned char *h = (unsigned char *)h_rec + len;
-            if (len + 16 > rec_cap || fread(h, 1, 16, fin) != 16) die("truncated container (chunk header)", NULL);
-            uint64_t pay = 0;
-            for (int j = 0; j < 4; j++) /* unpack_header, zip.c:393-399 */
-                pay += (uint64_t)h[4 * j] | ((uint64_t)h[4 * j + 1] << 8) | ((uint64_t)h[4 * j + 2] << 16) | ((uint64_t)(h[4 * j + 3] & 0x7f) << 24);
-            if (len + 16 + pay > rec_cap || fread(h + 16, 1, (size_t)pay, fin) != pay) die("truncated container (payload)", NULL);
-            len += 16 + pay;
-        }
-        start = now_sec();
-        uint64_t consumed = 0;
-        if (mrcz_copy_h2d(c, d_rec, h_rec, len)) die("H2D copy", c);
-        if (mrcz_uncompress_chunks(c, d_rec, len, nfl, chk, d_out, &consumed)) die("uncompress", c);
-        if (isTestThroughput != 1) {
-            if (mrcz_copy_d2h(c, h_out, d_out, nfl * 4)) die("D2H copy", c);
-        }
-        ctx->unzipTime += now_sec() - start;
-        if (isTestThroughput != 1) fwrite(h_out, sizeof(float), (size_t)nfl, fout); /* workers.c:627,668 */
-        done += nfl;
-        zbytes += len;
-    }
-    /* workers.c:679-685: decoded bytes and compressed bytes (plane payloads; chunk headers are not counted there) */
+    pipe_t p;
+    memset(&p, 0, sizeof(p));
+    p.s = ses; p.c = ses->e->c; p.fin = fin; p.fout = fout; p.decode = 1; p.chk = chk; p.total_floats = nfloats; p.batch_chunks = batch;
+    run_pipeline(&p);
+    const double elapsed = now_sec() - begin;
+    ctx->unzipTime += elapsed;
+    /* workers.c:675-685: the per-plane table; decoded bytes and compressed bytes (plane payloads; chunk headers are not counted) */
+    uint64_t f4[4] = {nfloats, nfloats, nfloats, nfloats};
+    print_result_table(f4, p.plane_z, 0.0, elapsed, "Decompress Result Info");
     ctx->allFileSize += nfloats * 4;
-    ctx->allZipFileSize += zbytes - 16 * ((nfloats + chk - 1) / chk);
+    for (int j = 0; j < 4; j++) ctx->allZipFileSize += p.plane_z[j];
     return 0;
 }

@@ -96,6 +96,37 @@ int mrcz_host_free(mrcz_ctx_t *ctx, void *h_ptr);
 int mrcz_copy_h2d(mrcz_ctx_t *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int mrcz_copy_d2h(mrcz_ctx_t *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 
+/*
+ * Asynchronous forms, for pipelines that overlap file I/O, PCIe copies and the codec (the chunk scheduler of
+ * host/workers_gpu.c, which replaces the one-chunk-at-a-time loops of src/core/workers.c:779-855 and :592-672).
+ * A context owns three HIP streams -- compute, upload, download -- and events order work across them:
+ *
+ *   mrcz_copy_h2d_async(c, MRCZ_STREAM_UPLOAD, d_in, h_pinned, n);  mrcz_event_record(c, MRCZ_STREAM_UPLOAD, up);
+ *   mrcz_stream_wait_event(c, MRCZ_STREAM_COMPUTE, up);
+ *   mrcz_compress_chunks_async(c, d_in, nfloats, first_chunk, bits, d_rec, cap, h_res5);
+ *   mrcz_event_record(c, MRCZ_STREAM_COMPUTE, done);   ...   mrcz_event_sync(c, done);   // h_res5[0] = bytes written
+ *
+ * Nothing here blocks the host except mrcz_event_sync.  Result words are written to PINNED host memory
+ * (mrcz_host_malloc) in stream order: compress h_result5 = { bytes written, plane_bytes[4] }, uncompress h_result3 =
+ * { record bytes consumed, error count (non-zero = MRCZ_EFORMAT), streams decoded sequentially }.  Calls on one
+ * context must be issued by one thread at a time (the workspace is reused in stream order).
+ */
+#define MRCZ_STREAM_COMPUTE 0
+#define MRCZ_STREAM_UPLOAD 1
+#define MRCZ_STREAM_DOWNLOAD 2
+typedef struct mrcz_event mrcz_event_t;
+int mrcz_event_create(mrcz_ctx_t *ctx, mrcz_event_t **ev);
+void mrcz_event_destroy(mrcz_ctx_t *ctx, mrcz_event_t *ev);
+int mrcz_event_record(mrcz_ctx_t *ctx, int stream_id, mrcz_event_t *ev);      /* ev = everything enqueued so far on that stream */
+int mrcz_stream_wait_event(mrcz_ctx_t *ctx, int stream_id, mrcz_event_t *ev); /* later work of that stream starts after ev */
+int mrcz_event_sync(mrcz_ctx_t *ctx, mrcz_event_t *ev);                       /* the host waits for ev */
+int mrcz_copy_h2d_async(mrcz_ctx_t *ctx, int stream_id, void *d_dst, const void *h_src, uint64_t bytes);
+int mrcz_copy_d2h_async(mrcz_ctx_t *ctx, int stream_id, void *h_dst, const void *d_src, uint64_t bytes);
+int mrcz_compress_chunks_async(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk, int bits,
+                               void *d_out, uint64_t out_cap, uint64_t *h_result5);
+int mrcz_uncompress_chunks_async(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
+                                 void *d_out, uint64_t *h_result3);
+
 /* apply_mask alone on device (the erasebytes restatement used by the GPU-side verification tools,
  * src/tool/erasebytes.c:109-134): words [256, nwords) of a file &= mask(bits).  In place. */
 int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, uint64_t first_word_index, int bits);

@@ -124,11 +124,25 @@ def _accounting_row(stdout: str):
     raise AssertionError("no accounting row in:\n" + stdout)
 
 
+def _plane_table(stdout: str):
+    """print_result (zip.c:401-466): [(before, after)] of the four byte streams + the 'Whole File' row"""
+    rows = []
+    for l in stdout.splitlines():
+        f = l.split()
+        if len(f) == 4 and f[0] in ("0", "1", "2", "3") and f[1].isdigit() and f[2].isdigit():
+            rows.append((int(f[1]), int(f[2])))
+        elif l.startswith("Whole File"):
+            rows.append((int(f[2]), int(f[3])))
+    assert len(rows) == 5, stdout
+    return rows
+
+
 @pytest.mark.skipif(util.ref_binary("mrc_tar_c") is None, reason="oracle/_ref not present on this box")
 def test_ctx_accounting_matches_the_reference(tmp_path):
-    """SURVEY a15: zip -> allZipFileSize == container size - 17 (sum of payload + 4-byte plane headers, workers.c:870-873);
-    unzip -> allFileSize == 4 * floats, allZipFileSize == payload bytes (workers.c:679-685).  Same numbers as the
-    reference binary prints on the same input."""
+    """SURVEY a15: zip -> sum of mzip_t.zfsz == container size - 17 (payload + 4-byte plane headers, workers.c:870-873);
+    unzip -> allFileSize == 4 * floats, allZipFileSize == payload bytes (workers.c:679-685).  The per-plane table
+    (print_result, zip.c:401-466) and the context row (common.c:66-90) carry the same numbers as the reference binary
+    prints on the same input."""
     exe, ref = os.path.join(BIN, "mrc_tar"), util.ref_binary("mrc_tar_c")
     n = util.CHUNK + 54321
     w = util.gauss_words(n, seed=5)
@@ -137,12 +151,15 @@ def test_ctx_accounting_matches_the_reference(tmp_path):
     r = _run([exe, "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip"])
     rr = _run([ref, "-i", str(src), "-o", str(zr), "-b", "8", "-t", "zip"])
     assert r.returncode == 0 and rr.returncode == 0
-    fs, zs = _accounting_row(r.stdout)
+    t = _plane_table(r.stdout)
+    assert t == _plane_table(rr.stdout)
+    assert t[4] == (4 * n, os.path.getsize(z) - 17)
+    fs, zs = _accounting_row(r.stdout)                  # our mrc_tar also prints the context row after a zip
     assert (fs, zs) == (4 * n + 2, os.path.getsize(z) - 17)
-    assert (fs, zs) == _accounting_row(rr.stdout)
     r = _run([exe, "-i", str(z), "-o", str(b), "-t", "unzip"])
     rr = _run([ref, "-i", str(zr), "-o", str(tmp_path / "rb"), "-t", "unzip"])
     assert r.returncode == 0 and rr.returncode == 0
+    assert _plane_table(r.stdout) == _plane_table(rr.stdout)
     fs, zs = _accounting_row(r.stdout)
     assert (fs, zs) == (4 * n, os.path.getsize(z) - 17 - 16 * 2)
     assert (fs, zs) == _accounting_row(rr.stdout)

@@ -5,6 +5,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
+#include <sys/mman.h>
+#include <fcntl.h>
+#include <unistd.h>
 static double now(void) { struct timeval tv; gettimeofday(&tv, NULL); return tv.tv_sec + tv.tv_usec * 1e-6; }
 int main(int argc, char **argv)
 {
@@ -43,6 +46,47 @@ int main(int argc, char **argv)
            "\"d2h_%lluMB_s\": %.4f, \"first_uncompress_s\": %.4f, \"second_uncompress_s\": %.4f}\n",
            nd, rc, batch, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6, t8 - t7, t9 - t8, (unsigned long long)(olen >> 20), t10 - t9,
            t11 - t10, t12 - t11);
+    /* host I/O paths: fread from /dev/shm into pinned memory, H2D from pageable and from mmap'ed memory */
+    {
+        const size_t N = 256u << 20;
+        const char *path = "/dev/shm/mrcz_probe.bin";
+        FILE *f = fopen(path, "wb");
+        fwrite(h2, 1, N, f);
+        fclose(f);
+        double a = now();
+        f = fopen(path, "rb");
+        size_t got = fread(h2, 1, N, f);
+        fclose(f);
+        double b = now();
+        char *pg = (char *)malloc(N);
+        f = fopen(path, "rb");
+        got += fread(pg, 1, N, f);
+        fclose(f);
+        double b2 = now();
+        mrcz_copy_h2d(c, d, pg, N);
+        double b3 = now();
+        mrcz_copy_h2d(c, d, pg, N);
+        double b4 = now();
+        int fd = open(path, O_RDONLY);
+        void *mm = mmap(NULL, N, PROT_READ, MAP_SHARED, fd, 0);
+        double b5 = now();
+        mrcz_copy_h2d(c, d, mm, N);
+        double b6 = now();
+        mrcz_copy_h2d(c, d, mm, N);
+        double b7 = now();
+        f = fopen("/dev/shm/mrcz_probe.out", "wb");
+        fwrite(h2, 1, N, f);
+        fclose(f);
+        double b8 = now();
+        printf("{\"fread_pinned_256MiB_s\": %.4f, \"fread_pageable_s\": %.4f, \"h2d_pageable_first_s\": %.4f, \"h2d_pageable_second_s\": %.4f, "
+               "\"mmap_s\": %.4f, \"h2d_mmap_first_s\": %.4f, \"h2d_mmap_second_s\": %.4f, \"fwrite_256MiB_s\": %.4f, \"got\": %zu}\n",
+               b - a, b2 - b, b3 - b2, b4 - b3, b5 - b4, b6 - b5, b7 - b6, b8 - b7, got);
+        munmap(mm, N);
+        close(fd);
+        unlink(path);
+        unlink("/dev/shm/mrcz_probe.out");
+        free(pg);
+    }
     mrcz_destroy(c);
     return rc;
 }
