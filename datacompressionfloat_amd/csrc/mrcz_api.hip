@@ -464,7 +464,8 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
         /* real blocks fill at most the planes' size; false candidates and 16-byte rounding get another half */
         ctx->scratch_bytes = (uint64_t)6 * ctx->max_chunks * CHK;
         if (ctx->scratch_bytes > 0xffffffffull * 16ull) ctx->scratch_bytes = 0xffffffffull * 16ull;
-        hipError_t e = hipMalloc((void **)&ctx->scratch, (size_t)ctx->scratch_bytes);
+        /* 16 bytes of slack on both sides: the merge reads whole 16-byte groups that begin or end in a neighbouring window */
+        hipError_t e = hipMalloc((void **)&ctx->scratch, (size_t)ctx->scratch_bytes + 32u);
         if (e != hipSuccess) { ctx->scratch = NULL; return fail(ctx, MRCZ_ENOMEM, "decode scratch", e); }
     }
     const uint8_t *rec = (const uint8_t *)d_records;
@@ -489,7 +490,7 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
             LAUNCH("k_cand_index", k_cand_index, dim3(1), dim3(256), ctx->ncand, ns, ctx->candbase);
             /* fixed grid: the workgroups pull candidate numbers from ctx->njobs[0] until it passes candbase[ns] (no read-back) */
             LAUNCH_S("k_blk_count", k_blk_count, dim3(ctx->blk_grid), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ns, ctx->candbase,
-                     ctx->cands, ctx->scratch, ctx->njobs + 2, (uint32_t)(ctx->scratch_bytes >> 4), ctx->hdrs, ctx->calltag, ctx->njobs,
+                     ctx->cands, ctx->scratch + 16, ctx->njobs + 2, (uint32_t)(ctx->scratch_bytes >> 4), ctx->hdrs, ctx->calltag, ctx->njobs,
                      ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL);
         }
         LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->segs, ctx->nseg, ctx->segidx,
@@ -497,8 +498,8 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
         LAUNCH_S("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
                  ctx->fallback, ctx->phase_profile == 1 ? ctx->dbgphase : (unsigned long long *)NULL);
         LAUNCH("k_inflate_seq", k_inflate, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
-        LAUNCH("k_merge_segments", k_merge_segments, dim3(512, nb), dim3(256), rec, ctx->scratch, ctx->planes, ctx->segs, ctx->nseg, ctx->segidx, bfl,
-               chk, out + c0 * chk);
+        LAUNCH("k_merge_segments", k_merge_segments, dim3(512, nb), dim3(256), rec, ctx->scratch + 16, ctx->planes, ctx->segs, ctx->nseg, ctx->segidx, bfl,
+               chk, out + c0 * chk, len, (uint64_t)4 * ctx->row_chunks * CHK);
     }
     HIPCHK(hipMemcpyAsync(h_res, ctx->result, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
     return MRCZ_OK;
@@ -535,7 +536,8 @@ extern "C" int mrcz_event_create(mrcz_ctx_t *ctx, mrcz_event_t **ev)
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     mrcz_event *e = (mrcz_event *)calloc(1, sizeof(mrcz_event));
     if (!e) return MRCZ_ENOMEM;
-    hipError_t r = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+    /* blocking sync: a host thread that waits for an event sleeps instead of spinning (the pipeline threads of several files share the cores) */
+    hipError_t r = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming | hipEventBlockingSync);
     if (r != hipSuccess) { free(e); return fail(ctx, MRCZ_EHIP, "hipEventCreate", r); }
     *ev = e;
     return MRCZ_OK;

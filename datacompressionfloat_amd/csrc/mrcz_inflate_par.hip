@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
  * One workgroup per tile of MTILE positions, wave w gathers plane w of the tile from its segments into LDS (16
  * destination-aligned bytes per lane and step, read at whatever alignment the source has -- gfx9 global memory takes
  * unaligned 16-byte loads), then every thread transposes 4 x 4 bytes and stores one uint4 of floats. */
-struct SegBases { const uint8_t *rec, *scratch, *planes; };
+struct SegBases { const uint8_t *rec, *scratch, *planes; uint64_t reclen, planes_bytes; };
 __device__ __forceinline__ const uint8_t *seg_base(const SegBases &sb, uint64_t src)
 {
     return ((src & SEG_REC) ? sb.rec : (src & SEG_PLANES) ? sb.planes : sb.scratch) + (src & SEG_OFFMASK);
@@ -1615,24 +1615,46 @@ __device__ __forceinline__ const uint8_t *seg_base(const SegBases &sb, uint64_t 
 __device__ __noinline__ uint4 merge_slow16(const SegBases sb, const Seg *__restrict__ sg, uint32_t ns, uint32_t p, uint32_t pend, uint32_t k)
 {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    uint32_t cdst = sg[k].dst, clen = sg[k].len;
+    Seg cur = sg[k];
+    const uint8_t *cb = seg_base(sb, cur.src);
     for (uint32_t q = 0; q < 16u; q++) {
         const uint32_t pp = p + q;
         uint32_t x = 0;
         if (pp < pend) {
-            while (pp >= cdst + clen && k + 1u < ns) { k++; cdst = sg[k].dst; clen = sg[k].len; }
-            if (pp >= cdst && pp < cdst + clen) x = pp < sg[k].fill_until ? (sg[k].fillb & 0xffu) : (uint32_t)seg_base(sb, sg[k].src)[pp - cdst];
+            while (pp >= cur.dst + cur.len && k + 1u < ns) { k++; cur = sg[k]; cb = seg_base(sb, cur.src); }
+            if (pp >= cur.dst && pp < cur.dst + cur.len) x = pp < cur.fill_until ? (cur.fillb & 0xffu) : (uint32_t)cb[pp - cur.dst];
         }
         const uint32_t sh = x << (8u * (q & 3u));
         if (q < 4u) w0 |= sh; else if (q < 8u) w1 |= sh; else if (q < 12u) w2 |= sh; else w3 |= sh;
     }
     return make_uint4(w0, w1, w2, w3);
 }
+/* may 16 bytes at byte offset `off` (possibly a little before the segment's start or past its end) of the buffer a segment
+ * lives in be read?  The scratch buffer has 16 bytes of slack on both sides of its allocation area. */
+__device__ __forceinline__ bool seg_can_overread(const SegBases &sb, uint64_t src, int64_t delta)
+{
+    const int64_t off = (int64_t)(src & SEG_OFFMASK) + delta;
+    if (src & SEG_REC) return off >= 0 && (uint64_t)off + 16u <= sb.reclen;
+    if (src & SEG_PLANES) return off >= 0 && (uint64_t)off + 16u <= sb.planes_bytes;
+    return true;
+}
+/* bytes [0, nlow) of a, the rest of b */
+__device__ __forceinline__ uint4 blend16(uint4 a, uint4 b, uint32_t nlow)
+{
+    uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, o[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t m = nlow >= 4u * (k + 1u) ? 0xffffffffu : (nlow <= 4u * k ? 0u : ((1u << (8u * (nlow - 4u * k))) - 1u));
+        o[k] = (av[k] & m) | (bv[k] & ~m);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
 
 __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restrict__ rec, const uint8_t *__restrict__ scratch,
                                                         const uint8_t *__restrict__ planes, const Seg *__restrict__ segs,
                                                         const uint32_t *__restrict__ nseg, const uint16_t *__restrict__ segidx,
-                                                        uint64_t nfloats, uint32_t chk, uint32_t *__restrict__ out)
+                                                        uint64_t nfloats, uint32_t chk, uint32_t *__restrict__ out, uint64_t reclen,
+                                                        uint64_t planes_bytes)
 {
     __shared__ __attribute__((aligned(16))) uint4 tile[4][MTILE / 16];
     const uint32_t c = blockIdx.y;
@@ -1643,7 +1665,7 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
     const Seg *sg = segs + (size_t)s * MAXSEG;
     const uint32_t ns = nseg[s];
     SegBases sb;
-    sb.rec = rec; sb.scratch = scratch; sb.planes = planes;
+    sb.rec = rec; sb.scratch = scratch; sb.planes = planes; sb.reclen = reclen; sb.planes_bytes = planes_bytes;
     for (uint32_t t = blockIdx.x; (uint64_t)t * MTILE < n; t += gridDim.x) {
         const uint32_t p0 = t * MTILE, pend = (n - p0) < (uint32_t)MTILE ? n : p0 + MTILE;
         /* nearly every tile lies in one segment or two: both are fetched with wave-uniform (scalar) loads */
@@ -1655,34 +1677,40 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
         if (k0 + 1u < ns) B = sg[k0 + 1u];
         const uint8_t *abase = seg_base(sb, A.src), *bbase = seg_base(sb, B.src);
         const uint32_t aend = A.dst + A.len, bend = B.dst + B.len;
+        /* A group of 16 bytes that straddles the boundary A | B (one per boundary) is read twice -- once relative to each
+         * segment, reading a few bytes past A's end and before B's start -- and blended: no byte loop, no dependent loads.
+         * Fill bytes near the boundary and sources that cannot be over-read (ends of the records) take the general path. */
+        const bool adj = B.len != 0u && B.dst == aend && A.len != 0u;
         /* four independent 16-byte loads per lane first (destination-aligned groups, source at any alignment), patches after */
-        uint4 v[MTILE / 16 / 64];
-        bool ok[MTILE / 16 / 64];
+        uint4 v[MTILE / 16 / 64], v2 = make_uint4(0, 0, 0, 0); /* (one boundary A | B: at most one straddling group per lane) */
+        uint32_t kind[MTILE / 16 / 64]; /* 0 zero, 1 inside A, 2 inside B, 3 straddles A | B, 4 general path */
 #pragma unroll
         for (int j = 0; j < MTILE / 16 / 64; j++) {
             const uint32_t g = (uint32_t)lane + 64u * (uint32_t)j, p = p0 + 16u * g;
+            const bool whole = ns != 0u && p + 16u <= pend;
             const bool inA = p >= A.dst && p + 16u <= aend, inB = p >= B.dst && p + 16u <= bend;
-            ok[j] = ns != 0u && p + 16u <= pend && (inA || inB);
-            const uint8_t *src = inA ? abase + (p - A.dst) : bbase + (p - B.dst);
+            uint32_t kd = (p < pend && ns) ? 4u : 0u;
+            if (whole && inA) kd = 1u;
+            else if (whole && inB) kd = 2u;
+            else if (whole && adj && p >= A.dst && p < aend && p + 16u <= bend && p >= A.fill_until && B.fill_until <= B.dst &&
+                     seg_can_overread(sb, A.src, (int64_t)(p - A.dst)) && seg_can_overread(sb, B.src, (int64_t)p - (int64_t)B.dst)) kd = 3u;
+            kind[j] = kd;
             v[j] = make_uint4(0, 0, 0, 0);
-            if (ok[j]) __builtin_memcpy(&v[j], src, 16);
+            if (kd == 1u || kd == 3u) __builtin_memcpy(&v[j], abase + (p - A.dst), 16);
+            if (kd == 2u) __builtin_memcpy(&v[j], bbase + (p - B.dst), 16);
+            if (kd == 3u) __builtin_memcpy(&v2, bbase + ((int64_t)p - (int64_t)B.dst), 16);
         }
 #pragma unroll
         for (int j = 0; j < MTILE / 16 / 64; j++) {
             const uint32_t g = (uint32_t)lane + 64u * (uint32_t)j, p = p0 + 16u * g;
-            if (ok[j]) {
-                const bool inA = p >= A.dst && p + 16u <= aend;
-                const uint32_t fu = inA ? A.fill_until : B.fill_until;
+            if (kind[j] == 1u || kind[j] == 2u) {
+                const uint32_t fu = kind[j] == 1u ? A.fill_until : B.fill_until;
                 if (p < fu) { /* leading repeats of a block: the previous block's last byte */
-                    const uint32_t nf = fu - p, fw = 0x01010101u * ((inA ? A.fillb : B.fillb) & 0xffu);
-                    uint32_t *vw = reinterpret_cast<uint32_t *>(&v[j]);
-#pragma unroll
-                    for (uint32_t k = 0; k < 4u; k++) {
-                        const uint32_t m = nf >= 4u * (k + 1u) ? 0xffffffffu : (nf <= 4u * k ? 0u : ((1u << (8u * (nf - 4u * k))) - 1u));
-                        vw[k] = (vw[k] & ~m) | (fw & m);
-                    }
+                    const uint32_t fw = 0x01010101u * ((kind[j] == 1u ? A.fillb : B.fillb) & 0xffu);
+                    v[j] = blend16(make_uint4(fw, fw, fw, fw), v[j], fu - p >= 16u ? 16u : fu - p);
                 }
-            } else if (p < pend && ns) v[j] = merge_slow16(sb, sg, ns, p, pend, k0); /* (a stream without segments -- malformed container -- stays zero) */
+            } else if (kind[j] == 3u) v[j] = blend16(v[j], v2, aend - p);
+            else if (kind[j] == 4u) v[j] = merge_slow16(sb, sg, ns, p, pend, k0);
             tile[w][g] = v[j];
         }
         __syncthreads();

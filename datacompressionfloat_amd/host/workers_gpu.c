@@ -40,6 +40,12 @@ static int g_batch_chunks = 8; /* chunks per device batch: 192 MiB of floats */
 
 void mrcz_workers_set_device(int device) { t_device = device; }
 void mrcz_workers_set_batch_chunks(int chunks) { g_batch_chunks = chunks < 1 ? 1 : (chunks > 128 ? 128 : chunks); }
+static int batch_chunks(void) /* MRCZ_BATCH_CHUNKS overrides the default (tests: several batches from small files) */
+{
+    const char *e = getenv("MRCZ_BATCH_CHUNKS");
+    if (e && atoi(e) > 0) mrcz_workers_set_batch_chunks(atoi(e));
+    return g_batch_chunks;
+}
 
 static void die(const char *what, mrcz_ctx_t *c)
 {
@@ -92,11 +98,12 @@ static pthread_mutex_t g_eng_mu = PTHREAD_MUTEX_INITIALIZER;
 static engine_t *engine_get(int device)
 {
     if (device < 0 || device >= MAXDEV) die("device index out of range", NULL);
+
     engine_t *e = &g_eng[device];
     pthread_mutex_lock(&g_eng_mu);
     if (!e->c) {
-        if (mrcz_create(&e->c, device, (uint32_t)g_batch_chunks) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
-        e->batch = g_batch_chunks;
+        e->batch = batch_chunks();
+        if (mrcz_create(&e->c, device, (uint32_t)e->batch) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
         pthread_mutex_init(&e->mu, NULL);
     }
     pthread_mutex_unlock(&g_eng_mu);
@@ -200,7 +207,16 @@ typedef struct {
     uint64_t zbytes;      /* uncompress: record bytes read */
     uint64_t nbatches;
     double gpu_time;      /* time the writer spent waiting for coded batches (what the reference counts as zip/unzip time) */
+    double t_fread, t_slotwait, t_fwrite, t_d2hwait, t_setup; /* MRCZ_TRACE=1: where the wall time of the call went */
 } pipe_t;
+
+static void trace_report(const pipe_t *p, const char *what, double elapsed, uint64_t bytes)
+{
+    if (!getenv("MRCZ_TRACE")) return;
+    fprintf(stderr, "[mrcz trace] %s: %.4f s (%.2f GB/s of floats), setup %.4f, reader: fread %.4f + slot waits %.4f, writer: waits for the codec %.4f, "
+            "copy-back waits %.4f, fwrite %.4f, batches %llu of %d chunks\n", what, elapsed, (double)bytes / elapsed / 1e9, p->t_setup, p->t_fread,
+            p->t_slotwait, p->gpu_time, p->t_d2hwait, p->t_fwrite, (unsigned long long)p->nbatches, p->batch_chunks);
+}
 
 static void *reader_main(void *arg)
 {
@@ -223,7 +239,10 @@ static void *reader_main(void *arg)
         uint64_t off = 0; /* bytes of the batch uploaded so far */
         for (int i = 0; i < p->batch_chunks && !eof; i++) {
             const int slot = (int)(chunk % R_IN);
+            double tt = now_sec();
             if (chunk >= R_IN) CK(mrcz_event_sync(c, s->in_ev[slot]), "event sync", c); /* the slot's previous upload is done */
+            p->t_slotwait += now_sec() - tt;
+            tt = now_sec();
             if (!s->h_in[slot]) CK(mrcz_host_malloc(c, &s->h_in[slot], IN_SLOT), "fail to alloc mem", c);
             unsigned char *h = (unsigned char *)s->h_in[slot];
             uint64_t bytes = 0;
@@ -256,6 +275,7 @@ static void *reader_main(void *arg)
                 p->zbytes += bytes;
                 if (done_floats >= p->total_floats) eof = 1;
             }
+            p->t_fread += now_sec() - tt;
             CK(mrcz_copy_h2d_async(c, MRCZ_STREAM_UPLOAD, (char *)s->d_a[b] + off, h, bytes), "H2D copy", c);
             CK(mrcz_event_record(c, MRCZ_STREAM_UPLOAD, s->in_ev[slot]), "event record", c);
             off += bytes;
@@ -320,8 +340,12 @@ static void *writer_main(void *arg)
                 }
                 const int os = (int)((oslice + written) % R_OUT);
                 const uint64_t o = written * OUT_SLOT, l = (out_bytes - o) < OUT_SLOT ? (out_bytes - o) : OUT_SLOT;
+                double tt = now_sec();
                 CK(mrcz_event_sync(c, s->out_ev[os]), "event sync", c);
+                p->t_d2hwait += now_sec() - tt;
+                tt = now_sec();
                 if (fwrite(s->h_out[os], 1, (size_t)l, p->fout) != l) die("fwrite", NULL); /* workers.c:837-850 / 627,668 */
+                p->t_fwrite += now_sec() - tt;
                 written++;
             }
             oslice += nsl;
@@ -395,7 +419,7 @@ int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const 
     const uint64_t fsz = get_file_size(fin);
     const uint64_t file_floats = fsz / 4u;
     if (file_floats == 0) return 0; /* workers.c:757: nothing is written when the first read is empty */
-    int batch = g_batch_chunks;
+    int batch = batch_chunks();
     const uint64_t file_chunks = (file_floats + CHUNK_SIZE - 1) / CHUNK_SIZE;
     if ((uint64_t)batch > file_chunks) batch = (int)file_chunks; /* a small file does not allocate a whole batch */
     session_t *ses = session_get((uint64_t)batch * CHUNK_BYTES, mrcz_records_bound((uint64_t)batch * CHUNK_SIZE) + 64);
@@ -410,8 +434,10 @@ int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const 
     pipe_t p;
     memset(&p, 0, sizeof(p));
     p.s = ses; p.c = ses->e->c; p.fin = fin; p.fout = fout; p.decode = 0; p.bits = bitsToMask; p.chk = CHUNK_SIZE; p.total_floats = file_floats; p.batch_chunks = batch;
+    p.t_setup = now_sec() - begin;
     run_pipeline(&p);
     const double elapsed = now_sec() - begin;
+    trace_report(&p, "run_compress", elapsed, file_floats * 4);
     ctx->zipTime += elapsed;
     /* workers.c:863-873: the per-plane table, then the sum of the per-plane compressed sizes (each includes its 4-byte header) */
     uint64_t f4[4] = {file_floats, file_floats, file_floats, file_floats};
@@ -441,7 +467,7 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
     const uint64_t nfloats = hd->fsz / COMPRESSION_PATH_NUM; /* workers.c:577 */
     if (nfloats == 0) return 0;
     const uint32_t chk = hd->chk;
-    int batch = g_batch_chunks;
+    int batch = batch_chunks();
     const uint64_t file_chunks = (nfloats + chk - 1) / chk;
     if ((uint64_t)batch > file_chunks) batch = (int)file_chunks;
     session_t *ses = session_get(mrcz_records_bound((uint64_t)batch * CHUNK_SIZE) + 64, (uint64_t)batch * CHUNK_BYTES);
@@ -450,8 +476,10 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
     pipe_t p;
     memset(&p, 0, sizeof(p));
     p.s = ses; p.c = ses->e->c; p.fin = fin; p.fout = fout; p.decode = 1; p.chk = chk; p.total_floats = nfloats; p.batch_chunks = batch;
+    p.t_setup = now_sec() - begin;
     run_pipeline(&p);
     const double elapsed = now_sec() - begin;
+    trace_report(&p, "run_uncompress", elapsed, nfloats * 4);
     ctx->unzipTime += elapsed;
     /* workers.c:675-685: the per-plane table; decoded bytes and compressed bytes (plane payloads; chunk headers are not counted) */
     uint64_t f4[4] = {nfloats, nfloats, nfloats, nfloats};

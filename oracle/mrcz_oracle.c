@@ -13,6 +13,7 @@
 
 #include <pthread.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -890,6 +891,70 @@ int64_t mrcz_oracle_uncompress(const uint8_t *zin, uint64_t zlen, uint8_t *out, 
 done:
     for (int j = 0; j < 4; j++) free(planes[j]);
     return ret;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * "-s int" mode (src/core/workers.c:125-175 encode, :444-511 decode; call sites :782-787, :604-609, :646-650)
+ * ---------------------------------------------------------------------------------------- */
+/* (char)round(buf[i]) of workers.c:137: libm round() = half away from zero on the float promoted to double, then the
+ * double -> char conversion.  Outside the range of char that conversion is undefined in C; what the reference does
+ * on x86-64 (every gcc, -O0 and -O2) is cvttsd2si to a 32-bit int -- which yields the "integer indefinite" 0x80000000
+ * for NaN and for anything outside [-2^31, 2^31) -- and then keeps the low byte.  Stated explicitly here so that the
+ * oracle does not depend on the compiler it is built with; pinned against oracle/_ref in tests/test_oracle.py. */
+uint8_t mrcz_oracle_float_to_int8(uint32_t word)
+{
+    float f;
+    memcpy(&f, &word, 4);
+    const double r = round((double)f);
+    int32_t i;
+    if (!(r >= -2147483648.0 && r < 2147483648.0)) i = INT32_MIN; /* also NaN */
+    else i = (int32_t)r;
+    return (uint8_t)((uint32_t)i & 0xffu);
+}
+
+/* convert_float_to_int (workers.c:125-148) on a zeroed int buffer (memset at workers.c:785): the first 256 words of
+ * the FILE are copied verbatim, every other word becomes its rounded value in the low byte, upper three bytes zero. */
+static void int_mode_convert(uint32_t *words, uint32_t num, int first)
+{
+    for (uint32_t i = first ? MRCZ_HEADER_WORDS : 0; i < num; i++) words[i] = mrcz_oracle_float_to_int8(words[i]);
+}
+
+/* run_compress with dataConvertedType == "int": the mask level is ignored (workers.c:786 passes a constant and
+ * split_convert_float_to_one_byte_stream never masks, :166) */
+int64_t mrcz_oracle_compress_int(const uint8_t *in, uint64_t fsz, uint8_t *out, uint64_t cap)
+{
+    uint64_t nfl = fsz / 4;
+    if (nfl == 0) return 0;
+    if (cap < mrcz_oracle_bound(fsz)) return -1;
+    put_file_header(out, fsz);
+    uint64_t op = MRCZ_FILE_HDR;
+    uint32_t *wbuf = (uint32_t *)malloc(sizeof(uint32_t) * MRCZ_CHUNK_SIZE);
+    int first = 1;
+    for (uint64_t off = 0; off < nfl; off += MRCZ_CHUNK_SIZE) {
+        uint32_t num = (uint32_t)((nfl - off) < MRCZ_CHUNK_SIZE ? (nfl - off) : MRCZ_CHUNK_SIZE);
+        memcpy(wbuf, in + 4 * off, (size_t)num * 4);
+        int_mode_convert(wbuf, num, first);
+        op += compress_chunk(wbuf, num, 0, first, out + op);
+        first = 0;
+    }
+    free(wbuf);
+    return (int64_t)op;
+}
+
+/* run_uncompress with dataConvertedType == "int": merge_one_byte_to_float_stream (workers.c:444-511) -- the first
+ * 256 words of the file are rebuilt from the four planes, every other word is (float)(signed char) of plane 0 */
+int64_t mrcz_oracle_uncompress_int(const uint8_t *zin, uint64_t zlen, uint8_t *out, uint64_t cap)
+{
+    const int64_t n = mrcz_oracle_uncompress(zin, zlen, out, cap);
+    if (n < 0) return n;
+    uint32_t chk;
+    memcpy(&chk, zin + 8, 4);
+    (void)chk;
+    for (uint64_t i = MRCZ_HEADER_WORDS; i < (uint64_t)n / 4; i++) {
+        const float f = (float)(signed char)out[4 * i];
+        memcpy(out + 4 * i, &f, 4);
+    }
+    return n;
 }
 
 /* ------------------------------------------------------------------------------------------

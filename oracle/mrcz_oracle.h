@@ -68,6 +68,12 @@ int64_t mrcz_oracle_compress(const uint8_t *in, uint64_t fsz, int bits, uint8_t 
  * Returns decoded length 4*floor(fsz/4), -1 on malformed input. */
 int64_t mrcz_oracle_uncompress(const uint8_t *zin, uint64_t zlen, uint8_t *out, uint64_t cap);
 
+/* "-s int" mode: src/core/workers.c:125-175 (encode), :444-511 (decode).  The quantiser alone ((char)round(x) with the
+ * x86-64 conversion of out-of-range values made explicit), and the two container functions. */
+uint8_t mrcz_oracle_float_to_int8(uint32_t word);
+int64_t mrcz_oracle_compress_int(const uint8_t *in, uint64_t fsz, uint8_t *out, uint64_t cap);
+int64_t mrcz_oracle_uncompress_int(const uint8_t *zin, uint64_t zlen, uint8_t *out, uint64_t cap);
+
 /* Debug/inspection used by the GPU parity tests: token + block tables of one plane stream. */
 typedef struct {
     uint32_t nsym;        /* symbols (literals + matches), END_BLOCK excluded */

@@ -45,20 +45,27 @@ SURVEY_D = {  # SURVEY.md Appendix D (reference + zlib 1.2.8): name -> {bits: (s
 }
 
 
-def ref_zip(data: bytes, bits: int) -> bytes:
+def ref_zip(data: bytes, bits: int, mode: str = "float") -> bytes:
     with tempfile.TemporaryDirectory() as d:
         i, o = os.path.join(d, "in"), os.path.join(d, "out.zip")
         open(i, "wb").write(data)
-        subprocess.check_call([REF, "-i", i, "-o", o, "-b", str(bits), "-t", "zip"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.check_call([REF, "-i", i, "-o", o, "-b", str(bits), "-t", "zip", "-s", mode], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         return open(o, "rb").read()
 
 
-def ref_unzip(z: bytes) -> bytes:
+def ref_unzip(z: bytes, mode: str = "float") -> bytes:
     with tempfile.TemporaryDirectory() as d:
         i, o = os.path.join(d, "in.zip"), os.path.join(d, "out")
         open(i, "wb").write(z)
-        subprocess.check_call([REF, "-i", i, "-o", o, "-t", "unzip"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.check_call([REF, "-i", i, "-o", o, "-t", "unzip", "-s", mode], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         return open(o, "rb").read()
+
+
+def int_cases():
+    """name -> input bytes for the "-s int" mode (workers.c:125-175,444-511): committed with the reference's containers"""
+    return {"int5000": util.int_mode_words(5000, seed=21).tobytes(),
+            "int300": util.int_mode_words(300, seed=22).tobytes(),               # 44 quantised words after the header
+            "int70001_tail2": util.int_mode_words(70001, seed=23).tobytes() + b"\x07\x08"}
 
 
 def small_cases():
@@ -90,14 +97,30 @@ def main():
         z = ref_zip(data, b)
         open(os.path.join(HERE, name + ".zip"), "wb").write(z)
         golden["small"][name] = {"bits": b, "input_bytes": len(data), "input_sha256": util.sha256(data), "size": len(z), "sha256": util.sha256(z)}
+    # "-s int" mode: containers and decoded outputs of the reference run with -s int
+    golden["int_mode"] = {}
+    for name, data in int_cases().items():
+        z = ref_zip(data, 5, "int")                      # the mask level is ignored in this mode (workers.c:786)
+        assert z == ref_zip(data, 0, "int")
+        open(os.path.join(HERE, name + ".zip"), "wb").write(z)
+        dec = ref_unzip(z, "int")
+        n = len(data) // 4
+        exp = util.int_mode_expected(np.frombuffer(data[: 4 * n], np.uint32)).tobytes()
+        assert dec == exp, name                          # the numpy statement of the quantiser agrees with the reference binary
+        golden["int_mode"][name] = {"input_bytes": len(data), "input_sha256": util.sha256(data), "size": len(z), "sha256": util.sha256(z),
+                                    "decoded_sha256": util.sha256(dec)}
     # larger seeded shapes (scaled to a few chunks): hashes only
     big = {
         "gauss_4Mi_b8": (util.gauss_words(4 * 1048576, seed=1234).tobytes(), 8),         # one partial chunk
         "gauss_16Mi_b8": (util.gauss_words(16 * 1048576, seed=1234).tobytes(), 8),       # config 1: 64 MiB, 3 chunks
         "poisson_7Mi_b0": (util.poisson_words(7 * 1048576, seed=7).tobytes(), 0),        # config 3 shape, 2 chunks
+        # config 3 at its full size (mrc_small_full.sh shape): 1024-byte header + 1024 x 1024 x 16 detector counts, b = 0 and 8
+        "poisson_mrc_small_b0": (util.poisson_words(256 + 16 * 1048576, seed=7).tobytes(), 0),
+        "poisson_mrc_small_b8": (util.poisson_words(256 + 16 * 1048576, seed=7).tobytes(), 8),
+        "int_mode_7Mi": (util.int_mode_words(7 * 1048576, seed=24).tobytes(), -1),       # -s int across a chunk boundary
     }
     for name, (data, b) in big.items():
-        z = ref_zip(data, b)
+        z = ref_zip(data, b) if b >= 0 else ref_zip(data, 0, "int")
         golden["large"][name] = {"bits": b, "input_bytes": len(data), "input_sha256": util.sha256(data), "size": len(z), "sha256": util.sha256(z)}
         print(name, len(z))
     json.dump(golden, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)

@@ -148,6 +148,7 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = 
 /* kernels run to completion at launch, in host order: cross-stream waits are satisfied by construction */
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 #define hipEventDisableTiming 2
+#define hipEventBlockingSync 1
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e3); return hipSuccess; }

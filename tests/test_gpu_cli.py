@@ -33,6 +33,27 @@ def test_mrc_tar_zip_unzip_matches_oracle(tmp_path, oracle):
         assert back.read_bytes() == util.erase_expected(w, bits).tobytes()
 
 
+def test_pipeline_over_many_small_batches(tmp_path, oracle):
+    """The reader / caller / writer pipeline of host/workers_gpu.c with one chunk per batch: 5 batches in flight over the two
+    device buffers and the ring slots (buffer reuse, event chains), both directions, bytes as the oracle's."""
+    exe = os.path.join(BIN, "mrc_tar")
+    n = 4 * util.CHUNK + 4321
+    w = util.gauss_words(n, seed=3)
+    src, dst, back = tmp_path / "in.mrc", tmp_path / "out.zip", tmp_path / "back.mrc"
+    src.write_bytes(w.tobytes())
+    env = dict(os.environ, MRCZ_BATCH_CHUNKS="1")
+    r = _run([exe, "-i", str(src), "-o", str(dst), "-b", "8", "-t", "zip"], env=env)
+    assert r.returncode == 0, r.stderr
+    ref = oracle.compress(w.tobytes(), 8, threads=8)
+    assert dst.read_bytes() == ref
+    r = _run([exe, "-i", str(dst), "-o", str(back), "-t", "unzip"], env=env)
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == util.erase_expected(w, 8).tobytes()
+    env2 = dict(os.environ, MRCZ_BATCH_CHUNKS="2")
+    assert _run([exe, "-i", str(src), "-o", str(dst), "-b", "8", "-t", "zip"], env=env2).returncode == 0
+    assert dst.read_bytes() == ref
+
+
 def test_mrc_tar_rejects_bad_arguments(tmp_path):
     exe = os.path.join(BIN, "mrc_tar")
     src = tmp_path / "in.mrc"

@@ -54,6 +54,40 @@ def poisson_words(n: int, seed: int = 7) -> np.ndarray:
     return w
 
 
+def int_mode_words(n: int, seed: int = 21) -> np.ndarray:
+    """Inputs for the "-s int" mode (workers.c:125-175): 256 header words, then floats that exercise the quantiser
+    (char)round(x): detector-like counts, exact .5 ties of both signs, values beyond [-128, 127] (the low byte of the
+    int32 conversion survives), values beyond int32, infinities, NaNs, denormals, and the int32 edge itself."""
+    rng = np.random.default_rng(seed)
+    f = rng.normal(20.0, 60.0, n).astype(np.float32)
+    f[::7] = np.round(f[::7]) + np.float32(0.5)          # ties: half away from zero
+    f[3::11] = -(np.abs(np.round(f[3::11])) + np.float32(0.5))
+    special = np.array([0.5, -0.5, 1.5, -1.5, 2.5, 126.5, 127.49, 127.5, 128.0, -128.5, -129.0, 255.0, 256.0, 300.7, -300.7,
+                        65535.6, 2147483520.0, 2147483648.0, -2147483648.0, -2147483904.0, 4294967296.0, 1e10, -1e10, 1e38,
+                        np.inf, -np.inf, np.nan, 1e-40, -1e-40, 0.0, -0.0, 0.49999997, -0.49999997, 8388607.5, 8388608.0], np.float32)
+    k = min(n, len(special) * 8)
+    if k:
+        f[-k:] = np.resize(special, k)
+    w = f.view(np.uint32).copy()
+    if n >= 256:
+        w[:256] = kat_words(256)                           # arbitrary header bits: copied verbatim, never quantised
+    return w
+
+
+def int_mode_expected(words: np.ndarray) -> np.ndarray:
+    """What unzip(-s int) of zip(-s int) returns (workers.c:444-511): header words verbatim, every other word
+    (float)(signed char)(char)round(x) with the x86-64 double -> int32 -> low byte conversion."""
+    f = words.view(np.float32).astype(np.float64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        r = np.where(f >= 0, np.floor(f + 0.5), np.ceil(f - 0.5))       # round(): half away from zero (exact in double)
+        ok = (r >= -2147483648.0) & (r < 2147483648.0)
+        i = np.where(ok, r, -2147483648.0).astype(np.int64)
+    q = (i & 0xff).astype(np.uint8).view(np.int8).astype(np.float32)
+    out = q.view(np.uint32).copy()
+    out[:256] = words[:256]
+    return out
+
+
 def runs_words(n: int, lens, alpha: int, seed: int = 3) -> np.ndarray:
     rng = np.random.default_rng(seed)
     out, tot = [], 0
@@ -97,6 +131,10 @@ class Oracle:
             getattr(lib, f).argtypes = [vp, u32, vp, u64]
         lib.mrcz_oracle_inflate.restype = i64
         lib.mrcz_oracle_inflate.argtypes = [vp, u64, vp, u64]
+        lib.mrcz_oracle_compress_int.restype = i64
+        lib.mrcz_oracle_compress_int.argtypes = [vp, u64, vp, u64]
+        lib.mrcz_oracle_uncompress_int.restype = i64
+        lib.mrcz_oracle_uncompress_int.argtypes = [vp, u64, vp, u64]
         lib.mrcz_oracle_erasebytes.restype = None
         lib.mrcz_oracle_erasebytes.argtypes = [vp, u64, i32]
 
@@ -112,12 +150,23 @@ class Oracle:
             raise RuntimeError("oracle compress failed")
         return out[:n].tobytes()
 
-    def uncompress(self, z: bytes) -> bytes:
+    def compress_int(self, data) -> bytes:
+        """run_compress with -s int (workers.c:782-787)"""
+        data = np.frombuffer(bytes(data), dtype=np.uint8)
+        cap = int(self.lib.mrcz_oracle_bound(len(data)))
+        out = np.empty(cap, np.uint8)
+        n = self.lib.mrcz_oracle_compress_int(data.ctypes.data, len(data), out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("oracle compress_int failed")
+        return out[:n].tobytes()
+
+    def uncompress(self, z: bytes, int_mode: bool = False) -> bytes:
         z = np.frombuffer(bytes(z), dtype=np.uint8)
         import struct
         fsz = struct.unpack("<Q", z[:8].tobytes())[0]
         out = np.empty(fsz // 4 * 4, np.uint8)
-        n = self.lib.mrcz_oracle_uncompress(z.ctypes.data, len(z), out.ctypes.data, len(out))
+        f = self.lib.mrcz_oracle_uncompress_int if int_mode else self.lib.mrcz_oracle_uncompress
+        n = f(z.ctypes.data, len(z), out.ctypes.data, len(out))
         if n < 0:
             raise RuntimeError("oracle uncompress failed")
         return out[:n].tobytes()
