@@ -32,6 +32,12 @@ def load():
     lib.mrcz_compress_chunks.argtypes = [vp, vp, u64, u64, i32, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     lib.mrcz_uncompress_chunks.restype = i32
     lib.mrcz_uncompress_chunks.argtypes = [vp, vp, u64, u64, u32, vp, ctypes.POINTER(u64)]
+    lib.mrcz_compress_chunks_int8.restype = i32
+    lib.mrcz_compress_chunks_int8.argtypes = [vp, vp, u64, u64, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    lib.mrcz_uncompress_chunks_int8.restype = i32
+    lib.mrcz_uncompress_chunks_int8.argtypes = [vp, vp, u64, u64, u32, u64, vp, ctypes.POINTER(u64)]
+    lib.mrcz_generate_kat_words.restype = i32
+    lib.mrcz_generate_kat_words.argtypes = [vp, vp, u64, u64]
     lib.mrcz_erase_bits.restype = i32
     lib.mrcz_erase_bits.argtypes = [vp, vp, u64, u64, i32]
     lib.mrcz_set_timing.restype = i32
@@ -51,4 +57,5 @@ EXPORTS = [
     "mrcz_host_malloc", "mrcz_host_free", "mrcz_copy_h2d", "mrcz_copy_d2h",
     "mrcz_event_create", "mrcz_event_destroy", "mrcz_event_record", "mrcz_stream_wait_event", "mrcz_event_sync",
     "mrcz_copy_h2d_async", "mrcz_copy_d2h_async", "mrcz_compress_chunks_async", "mrcz_uncompress_chunks_async",
+    "mrcz_generate_kat_words", "mrcz_compress_chunks_int8", "mrcz_uncompress_chunks_int8", "mrcz_compress_chunks_int8_async", "mrcz_uncompress_chunks_int8_async",
 ]

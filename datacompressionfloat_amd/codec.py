@@ -80,8 +80,9 @@ class MrcZipCodec:
         return int(_LIB.mrcz_records_bound(nfloats))
 
     # ---- device-resident API (what bench.py times) ----
-    def compress_device(self, words: torch.Tensor, bits: int, first_chunk: int = 0, out: torch.Tensor = None):
+    def compress_device(self, words: torch.Tensor, bits: int, first_chunk: int = 0, out: torch.Tensor = None, int_mode: bool = False):
         """words: cuda tensor of 32-bit elements (int32/float32/uint32 view), chunk-aligned start.
+        int_mode = the reference's "-s int" (src/core/workers.c:125-175): bits is ignored.
         Returns (records uint8 cuda tensor view, plane_bytes[4])."""
         assert words.is_cuda and words.is_contiguous() and words.element_size() == 4
         n = words.numel()
@@ -92,21 +93,30 @@ class MrcZipCodec:
         torch.cuda.current_stream(words.device).synchronize()
         olen = ctypes.c_uint64()
         planes = (ctypes.c_uint64 * 4)()
-        rc = _LIB.mrcz_compress_chunks(self._ctx, words.data_ptr(), n, first_chunk, bits, out.data_ptr(), out.numel(),
-                                       ctypes.byref(olen), planes)
+        if int_mode:
+            rc = _LIB.mrcz_compress_chunks_int8(self._ctx, words.data_ptr(), n, first_chunk, out.data_ptr(), out.numel(),
+                                                ctypes.byref(olen), planes)
+        else:
+            rc = _LIB.mrcz_compress_chunks(self._ctx, words.data_ptr(), n, first_chunk, bits, out.data_ptr(), out.numel(),
+                                           ctypes.byref(olen), planes)
         if rc != 0:
             raise self._err("mrcz_compress_chunks", rc)
         return out[: olen.value], [int(p) for p in planes]
 
-    def uncompress_device(self, records: torch.Tensor, nfloats: int, chk: int = CHUNK_FLOATS, out: torch.Tensor = None):
+    def uncompress_device(self, records: torch.Tensor, nfloats: int, chk: int = CHUNK_FLOATS, out: torch.Tensor = None,
+                          int_mode: bool = False, first_chunk: int = 0):
         assert records.is_cuda and records.dtype == torch.uint8 and records.is_contiguous()
         if out is None:
             out = torch.empty(nfloats, dtype=torch.int32, device=records.device)
         assert out.is_cuda and out.numel() >= nfloats and out.element_size() == 4
         torch.cuda.current_stream(records.device).synchronize()
         consumed = ctypes.c_uint64()
-        rc = _LIB.mrcz_uncompress_chunks(self._ctx, records.data_ptr(), records.numel(), nfloats, chk, out.data_ptr(),
-                                         ctypes.byref(consumed))
+        if int_mode:
+            rc = _LIB.mrcz_uncompress_chunks_int8(self._ctx, records.data_ptr(), records.numel(), nfloats, chk, first_chunk, out.data_ptr(),
+                                                  ctypes.byref(consumed))
+        else:
+            rc = _LIB.mrcz_uncompress_chunks(self._ctx, records.data_ptr(), records.numel(), nfloats, chk, out.data_ptr(),
+                                             ctypes.byref(consumed))
         if rc != 0:
             raise self._err("mrcz_uncompress_chunks", rc)
         return out[:nfloats], int(consumed.value)
@@ -119,9 +129,20 @@ class MrcZipCodec:
             raise self._err("mrcz_erase_bits", rc)
         return words
 
+    def generate_kat_device(self, words: torch.Tensor, first_index: int = 0):
+        """fill `words` (cuda, 32-bit elements) with words [first_index, ...) of the SURVEY App. D integer generator"""
+        assert words.is_cuda and words.is_contiguous() and words.element_size() == 4
+        torch.cuda.current_stream(words.device).synchronize()
+        rc = _LIB.mrcz_generate_kat_words(self._ctx, words.data_ptr(), first_index, words.numel())
+        if rc != 0:
+            raise self._err("mrcz_generate_kat_words", rc)
+        return words
+
     # ---- file-image API: same bytes as `mrc_tar_c -t zip|unzip` reads/writes ----
-    def zip_bytes(self, data: bytes, bits: int) -> bytes:
-        """run_compress on an in-memory file image (src/core/workers.c:690-881)."""
+    def zip_bytes(self, data: bytes, bits: int, mode: str = "float") -> bytes:
+        """run_compress on an in-memory file image (src/core/workers.c:690-881); mode = dataConvertedType ("float" | "int")."""
+        if mode not in ("float", "int"):
+            raise MrczError("mode must be 'float' or 'int' (mrc_tar -s)")
         if bits < 0 or bits > 32:
             raise MrczError("bits must be in 0..32 (src/core/workers.c:29-37 has 33 table entries)")
         fsz = len(data)
@@ -130,11 +151,12 @@ class MrcZipCodec:
             return b""  # src/core/workers.c:757: nothing is written when the first read is empty
         host = torch.frombuffer(bytearray(data[: nfl * 4]), dtype=torch.int32)
         dev = host.to(self.device)
-        rec, _ = self.compress_device(dev, bits, 0)
+        rec, _ = self.compress_device(dev, bits, 0, int_mode=(mode == "int"))
         return pack_file_header(fsz) + rec.cpu().numpy().tobytes()
 
-    def unzip_bytes(self, container: bytes) -> bytes:
-        """read_mrczip_header + run_uncompress (src/core/workers.c:568-688)."""
+    def unzip_bytes(self, container: bytes, mode: str = "float") -> bytes:
+        """read_mrczip_header + run_uncompress (src/core/workers.c:568-688); mode as for zip_bytes (the container does not
+        record it: the reference needs -s int again on decode)."""
         fsz, chk, typ, ztypes = unpack_file_header(container)
         if any(z != 0 for z in ztypes):
             raise MrczError("only ZLIB_DEF byte streams (ztype 0) are supported")
@@ -144,5 +166,5 @@ class MrcZipCodec:
         if nfl == 0:
             return b""
         rec = torch.frombuffer(bytearray(container[FILE_HEADER_BYTES:]), dtype=torch.uint8).to(self.device)
-        out, _ = self.uncompress_device(rec, nfl, chk)
+        out, _ = self.uncompress_device(rec, nfl, chk, int_mode=(mode == "int"))
         return out.cpu().numpy().tobytes()

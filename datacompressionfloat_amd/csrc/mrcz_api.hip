@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 using namespace mrcz;
 
@@ -107,10 +108,20 @@ static size_t inflate_par_lds() { return ((sizeof(ParShared) + 15u) & ~(size_t)1
 
 template <typename T> static hipError_t dalloc(T **p, size_t count) { return hipMalloc((void **)p, count * sizeof(T)); }
 
+static double wall_now()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chunks)
 {
     if (!out) return MRCZ_EINVAL;
     *out = NULL;
+    const bool trace = getenv("MRCZ_TRACE") != NULL;
+    const double t_begin = wall_now();
+    double t_dev = 0, t_streams = 0, t_alloc = 0;
     if (max_batch_chunks == 0) max_batch_chunks = 64;
     if (max_batch_chunks > 128) max_batch_chunks = 128; /* records of one batch stay < 4 GiB */
     int ndev = 0;
@@ -121,6 +132,7 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->device = device;
     ctx->max_chunks = max_batch_chunks;
     if (hipSetDevice(device) != hipSuccess) { free(ctx); return MRCZ_EHIP; }
+    t_dev = wall_now();
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
     ctx->lane_stream[0] = ctx->stream;
@@ -146,6 +158,7 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->huff_ht = 48;
     if (const char *ev = getenv("MRCZ_STAGGER")) ctx->stagger = atoi(ev) ? 1 : 0;
     if (const char *ev = getenv("MRCZ_HT")) { const int v = atoi(ev); if (v == 16 || v == 32 || v == 48) ctx->huff_ht = v; }
+    t_streams = wall_now();
     if (e == hipSuccess) e = dalloc(&ctx->tsum, ns * TPS);
     if (e == hipSuccess) e = dalloc(&ctx->tinfo, ns * TPS);
     if (e == hipSuccess) e = dalloc(&ctx->sinfo, ns);
@@ -178,6 +191,7 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    t_alloc = wall_now();
     /* the parallel inflate keeps its window, tables and a 32 KiB output stage in LDS (> 64 KiB) */
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_inflate_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_blk_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
@@ -185,6 +199,9 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
         mrcz_destroy(ctx);
         return e == hipErrorOutOfMemory ? MRCZ_ENOMEM : MRCZ_EHIP;
     }
+    if (trace)
+        fprintf(stderr, "[mrcz trace] mrcz_create: device %.4f s, streams + events %.4f, workspace %.4f, code object %.4f\n", t_dev - t_begin,
+                t_streams - t_dev, t_alloc - t_streams, wall_now() - t_alloc);
     *out = ctx;
     return MRCZ_OK;
 }
@@ -298,7 +315,7 @@ static int ensure_planes(mrcz_ctx *ctx)
  * offsets), phase 1 = layout in the output, phase 2 = zero + headers + emit.  The kernels index the workspace by the
  * lane-local stream number, so a lane is just a set of offset base pointers. */
 static int compress_lane(mrcz_ctx *ctx, hipStream_t lstream, int phase, int slot, uint32_t s0, const uint32_t *bin, uint64_t bfl,
-                         uint32_t nb, uint32_t mask, uint32_t fstart, uint8_t *out)
+                         uint32_t nb, uint32_t mask, uint32_t fstart, uint8_t *out, int int_mode)
 {
     const uint32_t ns = 4u * nb;
     TileSum *tsum = ctx->tsum + (size_t)s0 * TPS;
@@ -317,7 +334,8 @@ static int compress_lane(mrcz_ctx *ctx, hipStream_t lstream, int phase, int slot
     uint32_t *blkbase = ctx->blkbase + s0 + (uint32_t)slot; /* lane l needs 4 nb_l + 1 entries */
     uint8_t *planes = ctx->planes + (size_t)s0 * CHK;
     if (phase == 0) {
-        LAUNCH("k_tile_summary", k_tile_summary, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, tsum, planes);
+        if (int_mode) LAUNCH("k_tile_summary", k_tile_summary<true>, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, tsum, planes);
+        else LAUNCH("k_tile_summary", k_tile_summary<false>, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, tsum, planes);
         LAUNCH("k_stream_scan", k_stream_scan, dim3(ns), dim3(256), tsum, bfl, tinfo, sinfo, blkstart);
         LAUNCH("k_histogram", k_histogram, dim3(SPS, nb, 4), dim3(64), planes, bfl, tinfo, pairhist, blkstart, slideq);
         LAUNCH("k_block_reduce", k_block_reduce, dim3(MAXBLK, ns), dim3(64), tinfo, sinfo, pairhist, blkfreq);
@@ -344,7 +362,7 @@ static int compress_lane(mrcz_ctx *ctx, hipStream_t lstream, int phase, int slot
 /* enqueue a compress call on the context's compute stream(s); its five result words (bytes written, per-plane sums) are copied
  * to the pinned host words h_res[0..4] in stream order.  No host synchronisation. */
 static int compress_enqueue(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk, int bits, void *d_out, uint64_t out_cap,
-                            uint64_t *h_res)
+                            uint64_t *h_res, int int_mode)
 {
     if (!ctx || !d_in || !d_out || !h_res) return MRCZ_EINVAL;
     if (bits < 0 || bits > 32) return fail(ctx, MRCZ_EINVAL, "bits outside 0..32 (reference table has 33 entries, workers.c:29-37)", hipSuccess);
@@ -410,7 +428,7 @@ static int compress_enqueue(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats,
                 }
                 const uint32_t row0 = nlanes == 1u ? 0u : 4u * l * pc; /* first workspace row (stream slot) of this lane */
                 ctx->last_lc0[l] = cb; ctx->last_row0[l] = row0;
-                if (int rc = compress_lane(ctx, st, phase, (int)l, row0, in + c0 * CHK + f0, bfll, nbl, mask, fstart, out)) return rc;
+                if (int rc = compress_lane(ctx, st, phase, (int)l, row0, in + c0 * CHK + f0, bfll, nbl, mask, fstart, out, int_mode)) return rc;
                 if (phase == 1) {
                     HIPCHK(hipEventRecord(ctx->ev_cont, st), "event");
                     cont_pending = true;
@@ -433,7 +451,7 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
     if (!ctx || !out_len) return MRCZ_EINVAL;
     *out_len = 0;
     if (nfloats == 0) { ctx->ntimers = 0; return (d_in && d_out) ? MRCZ_OK : MRCZ_EINVAL; }
-    if (int rc = compress_enqueue(ctx, d_in, nfloats, first_chunk, bits, d_out, out_cap, ctx->h_result)) return rc;
+    if (int rc = compress_enqueue(ctx, d_in, nfloats, first_chunk, bits, d_out, out_cap, ctx->h_result, 0)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (compress)");
     *out_len = ctx->h_result[0];
     if (plane_bytes)
@@ -441,15 +459,36 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
     return MRCZ_OK;
 }
 
+/* "-s int" mode (src/core/workers.c:125-175, 782-787): the quantiser replaces the mask; the mask level plays no role */
+extern "C" int mrcz_compress_chunks_int8(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk,
+                                         void *d_out, uint64_t out_cap, uint64_t *out_len, uint64_t plane_bytes[4])
+{
+    if (!ctx || !out_len) return MRCZ_EINVAL;
+    *out_len = 0;
+    if (nfloats == 0) { ctx->ntimers = 0; return (d_in && d_out) ? MRCZ_OK : MRCZ_EINVAL; }
+    if (int rc = compress_enqueue(ctx, d_in, nfloats, first_chunk, 0, d_out, out_cap, ctx->h_result, 1)) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (compress)");
+    *out_len = ctx->h_result[0];
+    if (plane_bytes)
+        for (int j = 0; j < 4; j++) plane_bytes[j] = ctx->h_result[1 + j];
+    return MRCZ_OK;
+}
+extern "C" int mrcz_compress_chunks_int8_async(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk,
+                                               void *d_out, uint64_t out_cap, uint64_t *h_result5)
+{
+    return compress_enqueue(ctx, d_in, nfloats, first_chunk, 0, d_out, out_cap, h_result5, 1);
+}
+
 extern "C" int mrcz_compress_chunks_async(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk, int bits,
                                           void *d_out, uint64_t out_cap, uint64_t *h_result5)
 {
-    return compress_enqueue(ctx, d_in, nfloats, first_chunk, bits, d_out, out_cap, h_result5);
+    return compress_enqueue(ctx, d_in, nfloats, first_chunk, bits, d_out, out_cap, h_result5, 0);
 }
 
 /* enqueue an uncompress call; its three result words (record bytes consumed, error count, streams handed to the sequential
  * decoder) are copied to the pinned host words h_res[0..2] in stream order.  No host synchronisation. */
-static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk, void *d_out, uint64_t *h_res)
+static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk, void *d_out, uint64_t *h_res,
+                              int int_mode, uint64_t first_chunk)
 {
     if (!ctx || !d_out || !h_res) return MRCZ_EINVAL;
     ctx->ntimers = 0;
@@ -499,7 +538,7 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
                  ctx->fallback, ctx->phase_profile == 1 ? ctx->dbgphase : (unsigned long long *)NULL);
         LAUNCH("k_inflate_seq", k_inflate, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
         LAUNCH("k_merge_segments", k_merge_segments, dim3(512, nb), dim3(256), rec, ctx->scratch + 16, ctx->planes, ctx->segs, ctx->nseg, ctx->segidx, bfl,
-               chk, out + c0 * chk, len, (uint64_t)4 * ctx->row_chunks * CHK);
+               chk, out + c0 * chk, len, (uint64_t)4 * ctx->row_chunks * CHK, int_mode ? 1u : 0u, (first_chunk + c0) * (uint64_t)chk);
     }
     HIPCHK(hipMemcpyAsync(h_res, ctx->result, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream), "copy result");
     return MRCZ_OK;
@@ -511,7 +550,7 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
     if (!ctx || !d_out) return MRCZ_EINVAL;
     if (consumed) *consumed = 0;
     if (nfloats == 0) { ctx->ntimers = 0; return MRCZ_OK; }
-    if (int rc = uncompress_enqueue(ctx, d_records, len, nfloats, chk, d_out, ctx->h_result)) return rc;
+    if (int rc = uncompress_enqueue(ctx, d_records, len, nfloats, chk, d_out, ctx->h_result, 0, 0)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (uncompress)");
     if (consumed) *consumed = ctx->h_result[0];
     ctx->last_fallbacks = ctx->h_result[2];
@@ -522,7 +561,28 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
 extern "C" int mrcz_uncompress_chunks_async(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
                                             void *d_out, uint64_t *h_result3)
 {
-    return uncompress_enqueue(ctx, d_records, len, nfloats, chk, d_out, h_result3);
+    return uncompress_enqueue(ctx, d_records, len, nfloats, chk, d_out, h_result3, 0, 0);
+}
+
+/* "-s int" mode (src/core/workers.c:444-511, 604-609, 646-650): words past the file's first 256 become (float)(signed char) of
+ * their plane-0 byte; `first_chunk` = index in the FILE of the first chunk in d_records (the header words sit in chunk 0) */
+extern "C" int mrcz_uncompress_chunks_int8(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
+                                           uint64_t first_chunk, void *d_out, uint64_t *consumed)
+{
+    if (!ctx || !d_out) return MRCZ_EINVAL;
+    if (consumed) *consumed = 0;
+    if (nfloats == 0) { ctx->ntimers = 0; return MRCZ_OK; }
+    if (int rc = uncompress_enqueue(ctx, d_records, len, nfloats, chk, d_out, ctx->h_result, 1, first_chunk)) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (uncompress)");
+    if (consumed) *consumed = ctx->h_result[0];
+    ctx->last_fallbacks = ctx->h_result[2];
+    if (ctx->h_result[1]) return fail(ctx, MRCZ_EFORMAT, "malformed chunk records or deflate stream", hipSuccess);
+    return MRCZ_OK;
+}
+extern "C" int mrcz_uncompress_chunks_int8_async(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
+                                                 uint64_t first_chunk, void *d_out, uint64_t *h_result3)
+{
+    return uncompress_enqueue(ctx, d_records, len, nfloats, chk, d_out, h_result3, 1, first_chunk);
 }
 
 /* ---- events and the three streams of a context (pipelines: include/mrcz_hip.h) ---- */
@@ -644,6 +704,18 @@ extern "C" int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, 
     hipStream_t lstream = ctx->stream;
     LAUNCH("k_erase_bits", k_erase_bits, dim3(2048), dim3(256), (uint32_t *)d_words, nwords, first_word_index, mask_of(bits));
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (erase)");
+    return MRCZ_OK;
+}
+
+extern "C" int mrcz_generate_kat_words(mrcz_ctx_t *ctx, void *d_words, uint64_t first_index, uint64_t nwords)
+{
+    if (!ctx || !d_words) return MRCZ_EINVAL;
+    if (nwords == 0) return MRCZ_OK;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->ntimers = 0;
+    hipStream_t lstream = ctx->stream;
+    LAUNCH("k_generate_kat", k_generate_kat, dim3(4096), dim3(256), (uint32_t *)d_words, first_index, nwords);
+    HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (generate)");
     return MRCZ_OK;
 }
 

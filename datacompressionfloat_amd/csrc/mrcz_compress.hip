@@ -29,6 +29,7 @@ namespace mrcz {
 /* ======================================================================================
  * pass 1: tile summaries
  * ==================================================================================== */
+template <bool QUANT>
 __global__ __launch_bounds__(256) void k_tile_summary(const uint32_t *__restrict__ in, uint64_t nfloats,
                                                       uint32_t mask, uint32_t first_chunk_is_file_start,
                                                       TileSum *__restrict__ tsum, uint8_t *__restrict__ planes)
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void k_tile_summary(const uint32_t *__restrict
         const uint32_t t0 = g * SEG + ti * TILE;
         if (t0 >= n) break;
         const int len = (int)((n - t0) < (uint32_t)TILE ? (n - t0) : (uint32_t)TILE);
-        stage_tile(cin, t0, (uint32_t)len, mask, unmasked, lds);
+        stage_tile<QUANT>(cin, t0, (uint32_t)len, mask, unmasked, lds);
         __syncthreads();
         const uint8_t *plane = lds + w * PLANE_LDS;
         uint32_t x[16];

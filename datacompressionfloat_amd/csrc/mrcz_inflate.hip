@@ -260,4 +260,37 @@ __global__ __launch_bounds__(256) void k_erase_bits(uint32_t *__restrict__ w, ui
         if (first_word_index + i >= 256) w[i] &= mask;
 }
 
+/* Synthetic volumes for the large benchmark configurations, generated where they are used: the integer generator of
+ * SURVEY.md Appendix D (two LCG steps per word, 4096-word stripes of 10.0f), words [first, first + n).  The LCG state
+ * at any index comes from 32 squarings of the affine map s -> 1664525 s + 1013904223 (mod 2^32), so every thread starts
+ * its own run of 16 words independently; same words as tests/util.py kat_words(). */
+__global__ __launch_bounds__(256) void k_generate_kat(uint32_t *__restrict__ w, uint64_t first, uint64_t n)
+{
+    constexpr uint32_t A = 1664525u, C = 1013904223u;
+    constexpr uint64_t RUN = 16;
+    for (uint64_t r0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * RUN; r0 < n; r0 += (uint64_t)gridDim.x * 256 * RUN) {
+        const uint64_t i0 = first + r0;
+        /* state after 2 * i0 steps from s0 = 0x9E3779B9: (pa, pc) = f^(2 i0) */
+        uint32_t e = (uint32_t)(2ull * i0); /* the LCG has period 2^32 */
+        uint32_t pa = 1u, pc = 0u, ba = A, bc = C;
+        for (int b = 0; b < 32; b++) {
+            if (e & 1u) { pc = ba * pc + bc; pa = ba * pa; }
+            bc = ba * bc + bc;
+            ba = ba * ba;
+            e >>= 1;
+        }
+        uint32_t st = pa * 0x9E3779B9u + pc;
+        const uint64_t m = (n - r0) < RUN ? (n - r0) : RUN;
+        for (uint64_t j = 0; j < m; j++) {
+            st = st * A + C;
+            const uint32_t r = st;
+            st = st * A + C;
+            const uint32_t r2 = st;
+            uint32_t v = (((r2 >> 27) & 1u) << 31) | ((124u + ((r2 >> 28) & 7u)) << 23) | (r >> 9);
+            if ((((i0 + j) >> 12) & 3u) == 3u) v = 0x41200000u;
+            w[r0 + j] = v;
+        }
+    }
+}
+
 } /* namespace mrcz */

@@ -31,6 +31,7 @@
  * mrcz_inflate.hip.
  */
 #include "mrcz_common.h"
+#include "mrcz_tile.h"
 
 namespace mrcz {
 
@@ -1654,7 +1655,7 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
                                                         const uint8_t *__restrict__ planes, const Seg *__restrict__ segs,
                                                         const uint32_t *__restrict__ nseg, const uint16_t *__restrict__ segidx,
                                                         uint64_t nfloats, uint32_t chk, uint32_t *__restrict__ out, uint64_t reclen,
-                                                        uint64_t planes_bytes)
+                                                        uint64_t planes_bytes, uint32_t int_mode, uint64_t first_float)
 {
     __shared__ __attribute__((aligned(16))) uint4 tile[4][MTILE / 16];
     const uint32_t c = blockIdx.y;
@@ -1728,6 +1729,13 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
             o4.y = __byte_perm(ab_lo, cd_lo, 0x7632);
             o4.z = __byte_perm(ab_hi, cd_hi, 0x5410);
             o4.w = __byte_perm(ab_hi, cd_hi, 0x7632);
+            if (int_mode) { /* "-s int" (workers.c:444-511): past the file's 256 header words, word = (float)(signed char) plane 0 */
+                const uint64_t fi = first_float + cbase + i;
+                if (fi >= 256u) o4.x = dequant_int8(o4.x);
+                if (fi + 1u >= 256u) o4.y = dequant_int8(o4.y);
+                if (fi + 2u >= 256u) o4.z = dequant_int8(o4.z);
+                if (fi + 3u >= 256u) o4.w = dequant_int8(o4.w);
+            }
             uint32_t *o = out + cbase + i;
             if (i + 4u <= n && (((uintptr_t)o) & 15u) == 0) *reinterpret_cast<uint4 *>(o) = o4;
             else {

@@ -9,9 +9,31 @@
 
 namespace mrcz {
 
+/* "-s int" mode of the reference: (char)round(x) (src/core/workers.c:137), kept in the low byte of a zeroed int
+ * (workers.c:140-144, memset at :785).  round() is half away from zero; the double -> char conversion is done by x86-64
+ * as a 32-bit cvttsd2si (0x80000000 for NaN and anything outside [-2^31, 2^31)) followed by a truncation to the low byte --
+ * reproduced here bit for bit (pinned by the fixtures of tests/golden/make_golden.py, which run the reference binary). */
+__device__ __forceinline__ uint32_t quant_int8(uint32_t w)
+{
+    float f;
+    __builtin_memcpy(&f, &w, 4);
+    const float r = roundf(f);
+    if (!(r >= -2147483648.0f && r < 2147483648.0f)) return 0u; /* integer indefinite 0x80000000: low byte 0 */
+    return (uint32_t)(int32_t)r & 0xffu;
+}
+/* the inverse (merge_one_byte_to_float_stream, workers.c:444-511): (float)(signed char) of the low byte */
+__device__ __forceinline__ uint32_t dequant_int8(uint32_t w)
+{
+    const float f = (float)(int32_t)(int8_t)(w & 0xffu);
+    uint32_t o;
+    __builtin_memcpy(&o, &f, 4);
+    return o;
+}
+
 /* All 256 threads: stage tile [t0, t0+len) of one chunk into lds[4][PLANE_LDS].
  * cin = first word of the chunk; positions below `unmasked_below` (256 for chunk 0 of a file,
  * workers.c:90-94) keep all their bits. */
+template <bool QUANT>
 __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ cin, uint32_t t0, uint32_t len,
                                            uint32_t mask, uint32_t unmasked_below, uint8_t *lds)
 {
@@ -28,7 +50,12 @@ __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ cin, uin
             if (p + 2u < len) w2 = cin[t0 + p + 2u];
         }
         const uint32_t gp = t0 + p;
-        if (gp >= unmasked_below) {
+        if (QUANT) { /* "-s int": every word past the file header becomes its rounded value in one byte; no mask (workers.c:166) */
+            if (gp >= unmasked_below) w0 = quant_int8(w0);
+            if (gp + 1u >= unmasked_below) w1 = quant_int8(w1);
+            if (gp + 2u >= unmasked_below) w2 = quant_int8(w2);
+            if (gp + 3u >= unmasked_below) w3 = quant_int8(w3);
+        } else if (gp >= unmasked_below) {
             w0 &= mask; w1 &= mask; w2 &= mask; w3 &= mask;
         } else {
             if (gp + 1u >= unmasked_below) w1 &= mask;

@@ -127,9 +127,30 @@ int mrcz_compress_chunks_async(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloa
 int mrcz_uncompress_chunks_async(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
                                  void *d_out, uint64_t *h_result3);
 
+/*
+ * "-s int" mode of the reference (src/core/workers.c:125-175 encode, :444-511 decode; selected by `mrc_tar -s int`,
+ * call sites workers.c:782-787, 604-609, 646-650).  Encode: every word past the file's first 256 is replaced by
+ * (char)round(x) in its low byte (upper bytes zero), then the same plane split / DEFLATE / container; the mask level
+ * plays no role.  Decode: the same container, then word = (float)(signed char) of its plane-0 byte past the header
+ * words.  The container does not record the mode: the caller must ask for it again, as with the reference.
+ */
+int mrcz_compress_chunks_int8(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk,
+                              void *d_out, uint64_t out_cap, uint64_t *out_len, uint64_t plane_bytes[4]);
+int mrcz_uncompress_chunks_int8(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
+                                uint64_t first_chunk, void *d_out, uint64_t *consumed);
+int mrcz_compress_chunks_int8_async(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, uint64_t first_chunk,
+                                    void *d_out, uint64_t out_cap, uint64_t *h_result5);
+int mrcz_uncompress_chunks_int8_async(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats, uint32_t chk,
+                                      uint64_t first_chunk, void *d_out, uint64_t *h_result3);
+
 /* apply_mask alone on device (the erasebytes restatement used by the GPU-side verification tools,
  * src/tool/erasebytes.c:109-134): words [256, nwords) of a file &= mask(bits).  In place. */
 int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, uint64_t first_word_index, int bits);
+
+/* Synthetic benchmark volumes generated on the device: words [first_index, first_index + nwords) of the integer generator
+ * of SURVEY.md Appendix D (the known-answer inputs of the reference's containers; tests/util.py kat_words).  Lets a 64 GiB
+ * volume exist without a host copy.  Synchronous. */
+int mrcz_generate_kat_words(mrcz_ctx_t *ctx, void *d_words, uint64_t first_index, uint64_t nwords);
 
 /* When on, every kernel launch is bracketed by HIP events on the context's stream (adds a host
  * synchronisation per launch: use for profiling, not for throughput runs). */

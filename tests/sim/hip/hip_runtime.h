@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ucontext.h>
+#include <math.h>
 #include <type_traits>
 #include <functional>
 

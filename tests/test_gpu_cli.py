@@ -60,7 +60,6 @@ def test_mrc_tar_rejects_bad_arguments(tmp_path):
     src.write_bytes(util.gauss_words(1000).tobytes())
     assert _run([exe, "-i", str(src), "-o", str(tmp_path / "o"), "-b", "33"]).returncode != 0
     assert _run([exe, "-i", str(tmp_path / "missing"), "-o", str(tmp_path / "o")]).returncode != 0
-    assert _run([exe, "-i", str(src), "-o", str(tmp_path / "o"), "-s", "int"]).returncode != 0  # float mode only
 
 
 def test_mrc_tarx_file_list_naming_and_threads(tmp_path, oracle):
@@ -113,6 +112,21 @@ def test_cross_decode_with_the_reference_binary(tmp_path):
     assert _run([ref, "-i", str(z1), "-o", str(b1), "-t", "unzip"]).returncode == 0      # reference decodes GPU output
     assert _run([exe, "-i", str(z2), "-o", str(b2), "-t", "unzip"]).returncode == 0      # GPU decodes reference output
     assert b1.read_bytes() == b2.read_bytes() == util.erase_expected(w, 10).tobytes()
+
+
+@pytest.mark.skipif(util.ref_binary("mrc_tar_c") is None, reason="oracle/_ref not present on this box")
+def test_int_mode_cli_cross_decode_with_the_reference_binary(tmp_path):
+    """mrc_tar -s int (workers.c:782-787, 604-609): same container as the reference binary, each decodes the other's file"""
+    exe, ref = os.path.join(BIN, "mrc_tar"), util.ref_binary("mrc_tar_c")
+    w = util.int_mode_words(300000, seed=41)
+    src, z1, z2, b1, b2 = (tmp_path / n for n in ("in.mrc", "gpu.zip", "ref.zip", "b1", "b2"))
+    src.write_bytes(w.tobytes())
+    assert _run([exe, "-i", str(src), "-o", str(z1), "-t", "zip", "-s", "int"]).returncode == 0
+    assert _run([ref, "-i", str(src), "-o", str(z2), "-t", "zip", "-s", "int"]).returncode == 0
+    assert z1.read_bytes() == z2.read_bytes()
+    assert _run([ref, "-i", str(z1), "-o", str(b1), "-t", "unzip", "-s", "int"]).returncode == 0
+    assert _run([exe, "-i", str(z2), "-o", str(b2), "-t", "unzip", "-s", "int"]).returncode == 0
+    assert b1.read_bytes() == b2.read_bytes() == util.int_mode_expected(w).tobytes()
 
 
 def test_erasebytes_tool_matches_the_reference_tool(tmp_path):

@@ -76,7 +76,10 @@ def test_committed_reference_containers(codec):
 def test_seeded_volumes_match_reference_hashes(codec):
     gens = {"gauss_4Mi_b8": lambda: util.gauss_words(4 * 1048576, seed=1234),
             "gauss_16Mi_b8": lambda: util.gauss_words(16 * 1048576, seed=1234),
-            "poisson_7Mi_b0": lambda: util.poisson_words(7 * 1048576, seed=7)}
+            "poisson_7Mi_b0": lambda: util.poisson_words(7 * 1048576, seed=7),
+            # BASELINE config 3 at its full size: 1024-byte header + 1024 x 1024 x 16 detector counts (mrc_small_full.sh shape)
+            "poisson_mrc_small_b0": lambda: util.poisson_words(256 + 16 * 1048576, seed=7),
+            "poisson_mrc_small_b8": lambda: util.poisson_words(256 + 16 * 1048576, seed=7)}
     for name, gen in gens.items():
         meta = G["large"][name]
         data = gen().tobytes()
@@ -84,6 +87,29 @@ def test_seeded_volumes_match_reference_hashes(codec):
         z = codec.zip_bytes(data, meta["bits"])
         assert (len(z), util.sha256(z)) == (meta["size"], meta["sha256"]), name
         assert codec.unzip_bytes(z) == util.erase_expected(np.frombuffer(data, np.uint32), meta["bits"]).tobytes()
+
+
+def test_int_mode(codec, oracle):
+    """"-s int" of the reference (workers.c:125-175, 444-511): committed containers the reference wrote with -s int, the
+    oracle on a fresh input, a two-chunk volume by hash; decode = (float)(signed char)(char)round(x) past the header."""
+    from golden.make_golden import int_cases
+    for name, data in int_cases().items():
+        ref = open(os.path.join(util.GOLDEN, name + ".zip"), "rb").read()
+        assert codec.zip_bytes(data, 11, mode="int") == ref, name          # the mask level is ignored in this mode
+        n = len(data) // 4
+        exp = util.int_mode_expected(np.frombuffer(data[: 4 * n], np.uint32)).tobytes()
+        assert codec.unzip_bytes(ref, mode="int") == exp, name
+        assert util.sha256(exp) == G["int_mode"][name]["decoded_sha256"]
+    w = util.int_mode_words(500000, seed=31)
+    z = codec.zip_bytes(w.tobytes(), 0, mode="int")
+    assert z == oracle.compress_int(w.tobytes())
+    assert codec.unzip_bytes(z, mode="int") == util.int_mode_expected(w).tobytes()
+    meta = G["large"]["int_mode_7Mi"]
+    big = util.int_mode_words(7 * 1048576, seed=24)
+    assert util.sha256(big.tobytes()) == meta["input_sha256"]
+    z = codec.zip_bytes(big.tobytes(), 0, mode="int")
+    assert (len(z), util.sha256(z)) == (meta["size"], meta["sha256"])
+    assert codec.unzip_bytes(z, mode="int") == util.int_mode_expected(big).tobytes()
 
 
 def test_run_structures(codec, oracle):
@@ -194,6 +220,27 @@ def test_one_gib_roundtrip_property(codec):
     assert torch.equal(out, exp)
     # plane 0 is all zero after masking 8 bits: ~6 KiB per chunk; plane 1 is incompressible -> RAW
     assert rec.numel() < 0.6 * 4 * n
+    big.close()
+
+
+def test_eight_gib_multi_batch_roundtrip(codec, oracle):
+    """BASELINE config 4 shape on one GPU, scaled to 8 GiB: the SURVEY App. D volume generated on the device, 342 chunks through
+    a 128-chunk context = three batches inside ONE call each way (running record offset, header walk, scratch reuse, two
+    compress lanes per batch).  Too big for the oracle -> properties, plus the first chunk record against the oracle."""
+    import torch
+    n = 2 * 1024 * 1024 * 1024  # floats = 8 GiB
+    big = type(codec)(0, max_batch_chunks=128)
+    words = torch.empty(n, dtype=torch.int32, device="cuda")
+    big.generate_kat_device(words, 0)
+    assert np.array_equal(words[:100000].cpu().numpy().view(np.uint32), util.kat_words(100000))
+    rec, planes = big.compress_device(words, 8, 0)
+    assert sum(planes) == rec.numel()
+    first = oracle.compress(util.kat_words(util.CHUNK).tobytes(), 8)[17:]
+    assert rec[: len(first)].cpu().numpy().tobytes() == first          # chunk 0 of the volume == the oracle's container of that chunk
+    out, consumed = big.uncompress_device(rec, n)
+    assert consumed == rec.numel() and big.last_fallbacks() == 0
+    big.erase_bits_device(words, 8, 0)                                     # in place: words is now erasebytes(input)
+    assert torch.equal(out, words)
     big.close()
 
 

@@ -111,3 +111,33 @@ def test_edge_cases(oracle):
     assert len(z) == 17 + 16 + 4 and oracle.uncompress(z) == util.kat_words(1).tobytes()  # 4 RAW planes of 1 byte
     with pytest.raises(RuntimeError):
         oracle.compress(b"\0" * 64, 33)            # table has 33 entries (workers.c:29-37)
+
+
+def test_int_mode_oracle_matches_committed_reference_containers(oracle):
+    """"-s int" (workers.c:125-175, 444-511): containers the reference wrote with -s int (make_golden.py) and what it
+    decodes them to; inputs hold ties, values beyond char / int32, NaN and infinities (the x86-64 conversion made explicit)."""
+    from golden.make_golden import int_cases
+    for name, data in int_cases().items():
+        meta = G["int_mode"][name]
+        assert util.sha256(data) == meta["input_sha256"], "input generator drifted"
+        ref = open(os.path.join(util.GOLDEN, name + ".zip"), "rb").read()
+        assert util.sha256(ref) == meta["sha256"]
+        assert oracle.compress_int(data) == ref, name
+        dec = oracle.uncompress(ref, int_mode=True)
+        assert util.sha256(dec) == meta["decoded_sha256"]
+        n = len(data) // 4
+        assert dec == util.int_mode_expected(np.frombuffer(data[: 4 * n], np.uint32)).tobytes()
+
+
+@pytest.mark.skipif(util.ref_binary("mrc_tar_c") is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_int_mode_oracle_matches_live_reference_binary(oracle):
+    ref = util.ref_binary("mrc_tar_c")
+    w = util.int_mode_words(40000, seed=77)
+    with tempfile.TemporaryDirectory() as d:
+        src, dst, back = os.path.join(d, "i"), os.path.join(d, "o.zip"), os.path.join(d, "b")
+        w.tofile(src)
+        subprocess.check_call([ref, "-i", src, "-o", dst, "-b", "9", "-t", "zip", "-s", "int"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        z = open(dst, "rb").read()
+        assert oracle.compress_int(w.tobytes()) == z
+        subprocess.check_call([ref, "-i", dst, "-o", back, "-t", "unzip", "-s", "int"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert open(back, "rb").read() == oracle.uncompress(z, int_mode=True) == util.int_mode_expected(w).tobytes()

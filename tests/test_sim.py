@@ -53,3 +53,29 @@ def test_committed_reference_containers(simlib):
         n = len(data) // 4
         w = np.frombuffer(data[: 4 * n], np.uint32)
         assert simlib.compress_records(w, bits) == ref[17:], name
+
+
+def test_int_mode_matches_the_reference_containers(simlib, oracle):
+    """"-s int" (workers.c:125-175, 444-511): committed containers written by the reference with -s int, the oracle's
+    restatement, and the decoded words (float)(signed char)(char)round(x)."""
+    from golden.make_golden import int_cases
+    for name, data in int_cases().items():
+        ref = open(os.path.join(util.GOLDEN, name + ".zip"), "rb").read()
+        assert oracle.compress_int(data) == ref, name
+        n = len(data) // 4
+        w = np.frombuffer(data[: 4 * n], np.uint32)
+        assert simlib.compress_records(w, 0, int_mode=True) == ref[17:], name
+        exp = util.int_mode_expected(w)
+        assert np.array_equal(simlib.uncompress_records(ref[17:], n, int_mode=True), exp), name
+        assert oracle.uncompress(ref, int_mode=True) == exp.tobytes(), name
+
+
+def test_device_generator_equals_the_appendix_d_generator(simlib):
+    """mrcz_generate_kat_words (the on-device source of the 64 GiB benchmark volume) == tests/util.py kat_words, at any offset"""
+    ref = util.kat_words(70000)
+    assert np.array_equal(simlib.generate_kat(0, 70000), ref)
+    assert np.array_equal(simlib.generate_kat(12345, 40001), ref[12345:12345 + 40001])
+    assert np.array_equal(simlib.generate_kat(69999, 1), ref[69999:])
+    # the LCG has period 2^32 (two steps per word) and the stripe pattern period 2^14: word i + 2^31 == word i
+    assert np.array_equal(simlib.generate_kat((1 << 31) + 5, 9000), ref[5:9005])
+    assert np.array_equal(simlib.generate_kat((1 << 34) + (1 << 31) + 4090, 100), ref[4090:4190])

@@ -220,6 +220,9 @@ class SimCodec:
         lib.mrcz_records_bound.argtypes = [u64]
         lib.mrcz_compress_chunks.argtypes = [vp, vp, u64, u64, i32, vp, u64, ctypes.POINTER(u64), vp]
         lib.mrcz_uncompress_chunks.argtypes = [vp, vp, u64, u64, u32, vp, ctypes.POINTER(u64)]
+        lib.mrcz_compress_chunks_int8.argtypes = [vp, vp, u64, u64, vp, u64, ctypes.POINTER(u64), vp]
+        lib.mrcz_uncompress_chunks_int8.argtypes = [vp, vp, u64, u64, u32, u64, vp, ctypes.POINTER(u64)]
+        lib.mrcz_generate_kat_words.argtypes = [vp, vp, u64, u64]
         lib.mrcz_last_error.restype = ctypes.c_char_p
         lib.mrcz_last_error.argtypes = [vp]
         lib.mrcz_debug_fallbacks.restype = ctypes.c_int64
@@ -227,24 +230,35 @@ class SimCodec:
         self.ctx = vp()
         assert lib.mrcz_create(ctypes.byref(self.ctx), 0, max_batch_chunks) == 0
 
-    def compress_records(self, words: np.ndarray, bits: int, first_chunk: int = 0) -> bytes:
+    def compress_records(self, words: np.ndarray, bits: int, first_chunk: int = 0, int_mode: bool = False) -> bytes:
         n = len(words)
         din = aligned_empty(4 * n).view(np.uint32)
         din[:] = words
         cap = int(self.lib.mrcz_records_bound(n))
         dout = aligned_empty(cap + 8)
         olen = ctypes.c_uint64()
-        rc = self.lib.mrcz_compress_chunks(self.ctx, din.ctypes.data, n, first_chunk, bits, dout.ctypes.data, cap, ctypes.byref(olen), None)
+        if int_mode:
+            rc = self.lib.mrcz_compress_chunks_int8(self.ctx, din.ctypes.data, n, first_chunk, dout.ctypes.data, cap, ctypes.byref(olen), None)
+        else:
+            rc = self.lib.mrcz_compress_chunks(self.ctx, din.ctypes.data, n, first_chunk, bits, dout.ctypes.data, cap, ctypes.byref(olen), None)
         if rc != 0:
             raise RuntimeError(f"sim compress rc={rc}: {self.lib.mrcz_last_error(self.ctx)}")
         return dout[:olen.value].tobytes()
 
-    def uncompress_records(self, rec: bytes, nfloats: int, chk: int = CHUNK) -> np.ndarray:
+    def generate_kat(self, first: int, n: int) -> np.ndarray:
+        out = aligned_empty(4 * n).view(np.uint32)
+        assert self.lib.mrcz_generate_kat_words(self.ctx, out.ctypes.data, first, n) == 0
+        return out.copy()
+
+    def uncompress_records(self, rec: bytes, nfloats: int, chk: int = CHUNK, int_mode: bool = False) -> np.ndarray:
         r = aligned_empty(len(rec) + 8)
         r[:len(rec)] = np.frombuffer(rec, np.uint8)
         out = aligned_empty(4 * nfloats).view(np.uint32)
         cons = ctypes.c_uint64()
-        rc = self.lib.mrcz_uncompress_chunks(self.ctx, r.ctypes.data, len(rec), nfloats, chk, out.ctypes.data, ctypes.byref(cons))
+        if int_mode:
+            rc = self.lib.mrcz_uncompress_chunks_int8(self.ctx, r.ctypes.data, len(rec), nfloats, chk, 0, out.ctypes.data, ctypes.byref(cons))
+        else:
+            rc = self.lib.mrcz_uncompress_chunks(self.ctx, r.ctypes.data, len(rec), nfloats, chk, out.ctypes.data, ctypes.byref(cons))
         if rc != 0:
             raise RuntimeError(f"sim uncompress rc={rc}: {self.lib.mrcz_last_error(self.ctx)}")
         self.fallbacks = int(self.lib.mrcz_debug_fallbacks(self.ctx))

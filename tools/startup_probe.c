@@ -81,6 +81,29 @@ int main(int argc, char **argv)
         printf("{\"fread_pinned_256MiB_s\": %.4f, \"fread_pageable_s\": %.4f, \"h2d_pageable_first_s\": %.4f, \"h2d_pageable_second_s\": %.4f, "
                "\"mmap_s\": %.4f, \"h2d_mmap_first_s\": %.4f, \"h2d_mmap_second_s\": %.4f, \"fwrite_256MiB_s\": %.4f, \"got\": %zu}\n",
                b - a, b2 - b, b3 - b2, b4 - b3, b5 - b4, b6 - b5, b7 - b6, b8 - b7, got);
+        /* device -> host: into pinned, into fresh pageable memory, into a fresh mmap'ed tmpfs file */
+        {
+            double c0 = now();
+            mrcz_copy_d2h(c, h2, d, N);
+            double c1 = now();
+            char *pg2 = (char *)malloc(N);
+            mrcz_copy_d2h(c, pg2, d, N);
+            double c2 = now();
+            mrcz_copy_d2h(c, pg2, d, N);
+            double c3 = now();
+            int fo = open("/dev/shm/mrcz_probe.map", O_RDWR | O_CREAT | O_TRUNC, 0600);
+            if (ftruncate(fo, (off_t)N) != 0) perror("ftruncate");
+            void *mo = mmap(NULL, N, PROT_READ | PROT_WRITE, MAP_SHARED, fo, 0);
+            double c4 = now();
+            mrcz_copy_d2h(c, mo, d, N);
+            double c5 = now();
+            munmap(mo, N);
+            close(fo);
+            unlink("/dev/shm/mrcz_probe.map");
+            printf("{\"d2h_pinned_256MiB_s\": %.4f, \"d2h_pageable_first_s\": %.4f, \"d2h_pageable_second_s\": %.4f, \"d2h_fresh_mmap_file_s\": %.4f}\n",
+                   c1 - c0, c2 - c1, c3 - c2, c5 - c4);
+            free(pg2);
+        }
         munmap(mm, N);
         close(fd);
         unlink(path);
