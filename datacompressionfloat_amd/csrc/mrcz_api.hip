@@ -103,8 +103,7 @@ static int fail(mrcz_ctx *c, int code, const char *what, hipError_t e)
 
 /* Occupancy of the decode kernels is set by LDS: three 512-thread workgroups per CU need 3 x this <= 160 KiB, and the
  * hardware allocates LDS in 1280-byte granules (measured: at 54.4 KB only two workgroups were resident) */
-static_assert(((sizeof(ParShared) + 15u) & ~(size_t)15u) + 64u <= 42u * 1280u, "ParShared no longer fits three workgroups per CU");
-static size_t inflate_par_lds() { return ((sizeof(ParShared) + 15u) & ~(size_t)15u) + 64u; }
+static_assert(((sizeof(ParShared) + 15u) & ~(size_t)15u) <= 42u * 1280u, "ParShared no longer fits three workgroups per CU");
 
 template <typename T> static hipError_t dalloc(T **p, size_t count) { return hipMalloc((void **)p, count * sizeof(T)); }
 
@@ -138,6 +137,8 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->lane_stream[0] = ctx->stream;
     ctx->lanes = 2;
     if (const char *ev = getenv("MRCZ_LANES")) { const int v = atoi(ev); if (v >= 1 && v <= MAX_LANES) ctx->lanes = (uint32_t)v; }
+    if (max_batch_chunks < 8u) ctx->lanes = 1; /* batches under 8 chunks run as one lane anyway */
+    for (uint32_t l = 1; l < ctx->lanes && e == hipSuccess; l++) e = hipStreamCreate(&ctx->lane_stream[l]);
     {   /* the block decoder runs as a fixed grid of three workgroups per CU (its LDS footprint admits exactly three) */
         hipDeviceProp_t prop;
         ctx->blk_grid = 768;
@@ -147,7 +148,7 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     /* workspace rows (one per stream): every compress lane owns a fixed range of ceil(max_chunks / lanes) chunk rows */
     ctx->row_chunks = ctx->lanes * ((max_batch_chunks + ctx->lanes - 1u) / ctx->lanes);
     const size_t ns = 4u * (size_t)ctx->row_chunks;
-    for (int l = 1; l < MAX_LANES && e == hipSuccess; l++) e = hipStreamCreate(&ctx->lane_stream[l]);
+    /* (a HIP stream costs ~10 ms to create: only the lanes this context will use) */
     if (e == hipSuccess) e = hipStreamCreate(&ctx->up_stream);
     if (e == hipSuccess) e = hipStreamCreate(&ctx->down_stream);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming);
@@ -193,8 +194,6 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     t_alloc = wall_now();
     /* the parallel inflate keeps its window, tables and a 32 KiB output stage in LDS (> 64 KiB) */
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_inflate_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_blk_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_par_lds());
     if (e != hipSuccess) {
         mrcz_destroy(ctx);
         return e == hipErrorOutOfMemory ? MRCZ_ENOMEM : MRCZ_EHIP;
@@ -379,7 +378,7 @@ static int compress_enqueue(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats,
     if (int rc = ensure_planes(ctx)) return rc;
     HIPCHK(hipMemsetAsync(ctx->result, 0, 16 * sizeof(uint64_t), ctx->stream), "memset result");
     HIPCHK(hipEventRecord(ctx->ev_start, ctx->stream), "event");
-    for (int l = 1; l < MAX_LANES; l++) HIPCHK(hipStreamWaitEvent(ctx->lane_stream[l], ctx->ev_start, 0), "wait");
+    for (uint32_t l = 1; l < ctx->lanes; l++) HIPCHK(hipStreamWaitEvent(ctx->lane_stream[l], ctx->ev_start, 0), "wait");
     /* A batch runs as ctx->lanes lanes (contiguous parts of its chunks), one stream each: the Huffman kernel is
      * one tree's latency long (0.9 ms whatever the number of trees) and leaves most of the machine idle, so the other
      * lanes' streaming passes and emit kernels run under it, and the lanes' Huffman kernels under each other.  Only
@@ -437,7 +436,7 @@ static int compress_enqueue(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats,
         }
     }
     /* everything of the other lanes is done before the result is read back on the first */
-    for (int l = 1; l < MAX_LANES; l++) {
+    for (uint32_t l = 1; l < ctx->lanes; l++) {
         HIPCHK(hipEventRecord(ctx->ev_done[l], ctx->lane_stream[l]), "event");
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_done[l], 0), "wait");
     }
@@ -528,13 +527,13 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
                    ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag);
             LAUNCH("k_cand_index", k_cand_index, dim3(1), dim3(256), ctx->ncand, ns, ctx->candbase);
             /* fixed grid: the workgroups pull candidate numbers from ctx->njobs[0] until it passes candbase[ns] (no read-back) */
-            LAUNCH_S("k_blk_count", k_blk_count, dim3(ctx->blk_grid), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ns, ctx->candbase,
+            LAUNCH("k_blk_count", k_blk_count, dim3(ctx->blk_grid), dim3(PT), rec, len, ctx->dstreams, ns, ctx->candbase,
                      ctx->cands, ctx->scratch + 16, ctx->njobs + 2, (uint32_t)(ctx->scratch_bytes >> 4), ctx->hdrs, ctx->calltag, ctx->njobs,
                      ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL);
         }
         LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->segs, ctx->nseg, ctx->segidx,
                ctx->fallback, ctx->phase_profile == 1 ? 1u : 0u);
-        LAUNCH_S("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), inflate_par_lds(), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
+        LAUNCH("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
                  ctx->fallback, ctx->phase_profile == 1 ? ctx->dbgphase : (unsigned long long *)NULL);
         LAUNCH("k_inflate_seq", k_inflate, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
         LAUNCH("k_merge_segments", k_merge_segments, dim3(512, nb), dim3(256), rec, ctx->scratch + 16, ctx->planes, ctx->segs, ctx->nseg, ctx->segidx, bfl,

@@ -1366,8 +1366,9 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                                                   HdrCache *__restrict__ hdrs, uint32_t calltag, uint32_t *__restrict__ jobctr,
                                                   unsigned long long *__restrict__ dbg)
 {
-    HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
-    ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
+    /* static LDS (below the 64 KiB static limit): the compiler folds the structure's address into the instructions' offset
+     * fields; with a dynamic allocation every LDS access of the hot loops paid an extra address add */
+    __shared__ __attribute__((aligned(16))) ParShared sh;
     const int tid = threadIdx.x;
     const uint32_t total = candbase[nstreams];
     for (;;) {
@@ -1573,12 +1574,11 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
                                                     uint32_t *__restrict__ fallback, const uint32_t *__restrict__ only,
                                                     unsigned long long *__restrict__ dbg /* NULL, or 20 phase counters per stream */)
 {
-    HIP_DYNAMIC_SHARED(unsigned long long, dynsm)
-    ParShared &sh = *reinterpret_cast<ParShared *>(dynsm);
+    __shared__ __attribute__((aligned(16))) ParShared sh;
     const int tid = threadIdx.x;
     const uint32_t s = blockIdx.x;
     const DecStream d = ds[s];
-    if (d.raw) return;                  /* RAW planes are read straight from the payload by k_merge_planes */
+    if (d.raw) return;                  /* RAW planes are read straight from the payload by k_merge_segments */
     if (only && only[s] == 0) return;   /* already decoded block-parallel */
     const StreamView sv = make_view(rec, reclen, d, planes + (size_t)s * CHK);
     if (tid == 0) { sh.cur = 0; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }

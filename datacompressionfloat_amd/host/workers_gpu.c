@@ -20,6 +20,8 @@
  * src/core/zip.c:401-466); errors that the reference answers with exit(-1) (workers.c:708-712) do the
  * same here.  There is no CPU codec in this file: without a usable HIP device the call fails loudly.
  */
+#define _FILE_OFFSET_BITS 64
+#define _GNU_SOURCE
 #include "../../include/mrcz_hip.h"
 #include "../../include/mrcz_workers.h"
 
@@ -33,8 +35,9 @@ int isTestThroughput = 0; /* src/core/workers.c:39 */
 
 #define MAXDEV 16
 #define R_IN 4                    /* pinned input ring: chunk-sized slots */
-#define R_OUT 3                   /* pinned output ring */
-#define OUT_SLOT (32u << 20)      /* bytes per output slice */
+#define R_OUT 6                   /* pinned output ring */
+#define OUT_SLOT (16u << 20)      /* bytes per output slice */
+#define NWRITERS 3                /* threads that pwrite() finished slices (a single thread writes ~5.5 GB/s into the page cache) */
 #define CHUNK_BYTES ((uint64_t)CHUNK_SIZE * 4u)
 #define IN_SLOT (CHUNK_BYTES + 64u) /* a chunk of floats, or a chunk record (16-byte header + <= 4 RAW planes) */
 
@@ -212,6 +215,16 @@ typedef struct {
     uint64_t nbatches;
     double gpu_time;      /* time the writer spent waiting for coded batches (what the reference counts as zip/unzip time) */
     double t_fread, t_slotwait, t_fwrite, t_d2hwait, t_setup; /* MRCZ_TRACE=1: where the wall time of the call went */
+    /* output: slices of the result are written at their file offsets by NWRITERS threads (pwrite); fd_out < 0 = the output
+     * cannot seek, the writer thread fwrite()s the slices itself, in order */
+    int fd_out;
+    uint64_t out_off;                 /* file offset of the next result byte */
+    struct { int slot; uint64_t off, len; } wq[R_OUT];
+    int wq_head, wq_tail;             /* slices handed to the pwrite threads: [head, tail) */
+    int slot_busy[R_OUT];
+    int wq_done;                      /* no slice follows */
+    pthread_mutex_t wmu;
+    pthread_cond_t wcv;
 } pipe_t;
 
 static void trace_report(const pipe_t *p, const char *what, double elapsed, uint64_t bytes)
@@ -349,12 +362,48 @@ static void *reader_main(void *arg)
     return NULL;
 }
 
+static void *pwrite_main(void *arg)
+{
+    pipe_t *p = (pipe_t *)arg;
+    session_t *s = p->s;
+    for (;;) {
+        pthread_mutex_lock(&p->wmu);
+        while (p->wq_head == p->wq_tail && !p->wq_done) pthread_cond_wait(&p->wcv, &p->wmu);
+        if (p->wq_head == p->wq_tail) { pthread_mutex_unlock(&p->wmu); break; }
+        const int i = p->wq_head % R_OUT;
+        const int slot = p->wq[i].slot;
+        const uint64_t off = p->wq[i].off, len = p->wq[i].len;
+        p->wq_head++;
+        pthread_mutex_unlock(&p->wmu);
+        CK(mrcz_event_sync(p->c, s->out_ev[slot]), "event sync", p->c);
+        uint64_t done = 0;
+        while (done < len) {
+            const ssize_t w = pwrite(p->fd_out, (const char *)s->h_out[slot] + done, (size_t)(len - done), (off_t)(off + done));
+            if (w <= 0) die("pwrite", NULL);
+            done += (uint64_t)w;
+        }
+        pthread_mutex_lock(&p->wmu);
+        p->slot_busy[slot] = 0;
+        pthread_cond_broadcast(&p->wcv);
+        pthread_mutex_unlock(&p->wmu);
+    }
+    return NULL;
+}
+
 static void *writer_main(void *arg)
 {
     pipe_t *p = (pipe_t *)arg;
     session_t *s = p->s;
     mrcz_ctx_t *c = p->c;
     uint64_t oslice = 0; /* output ring position */
+    pthread_t pw[NWRITERS];
+    const int par = p->fd_out >= 0 && isTestThroughput != 1;
+    if (par) {
+        pthread_mutex_init(&p->wmu, NULL);
+        pthread_cond_init(&p->wcv, NULL);
+        for (int i = 0; i < NWRITERS; i++)
+            if (pthread_create(&pw[i], NULL, pwrite_main, p) != 0) die("pthread_create", NULL);
+    }
     for (uint64_t k = 0;; k++) {
         const int b = (int)(k & 1u);
         pthread_mutex_lock(&p->mu);
@@ -374,9 +423,34 @@ static void *writer_main(void *arg)
             if (s->h_res[b][1] != 0 || s->h_res[b][0] != bt.in_bytes) die("uncompress: malformed chunk records or deflate stream", NULL);
             out_bytes = bt.units * 4u;
         }
-        if (isTestThroughput != 1) {
-            /* slices of the result through the pinned output ring: the copy of slice j+1 runs while slice j is written */
-            const uint64_t nsl = (out_bytes + OUT_SLOT - 1) / OUT_SLOT;
+        const uint64_t nsl = (out_bytes + OUT_SLOT - 1) / OUT_SLOT;
+        if (isTestThroughput == 1 || nsl == 0) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->down_ev[b]), "event record", c);
+        else if (par) {
+            /* every slice: wait for a free ring slot, start its copy, hand it to the pwrite threads */
+            for (uint64_t j = 0; j < nsl; j++) {
+                const int os = (int)((oslice + j) % R_OUT);
+                double tt = now_sec();
+                pthread_mutex_lock(&p->wmu);
+                while (p->slot_busy[os]) pthread_cond_wait(&p->wcv, &p->wmu);
+                p->slot_busy[os] = 1;
+                pthread_mutex_unlock(&p->wmu);
+                p->t_fwrite += now_sec() - tt;
+                if (!s->h_out[os]) CK(mrcz_host_malloc(c, &s->h_out[os], OUT_SLOT), "fail to alloc mem", c);
+                const uint64_t o = j * OUT_SLOT, l = (out_bytes - o) < OUT_SLOT ? (out_bytes - o) : OUT_SLOT;
+                CK(mrcz_copy_d2h_async(c, MRCZ_STREAM_DOWNLOAD, s->h_out[os], (char *)s->d_b[b] + o, l), "D2H copy", c);
+                CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->out_ev[os]), "event record", c);
+                if (j + 1 == nsl) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->down_ev[b]), "event record", c);
+                pthread_mutex_lock(&p->wmu);
+                const int i = p->wq_tail % R_OUT;
+                p->wq[i].slot = os; p->wq[i].off = p->out_off + o; p->wq[i].len = l;
+                p->wq_tail++;
+                pthread_cond_broadcast(&p->wcv);
+                pthread_mutex_unlock(&p->wmu);
+            }
+            oslice += nsl;
+        } else {
+            /* the output cannot seek: slices through the pinned ring, written here in order (the copy of slice j+1 runs while
+             * slice j is written) */
             uint64_t issued = 0, written = 0;
             while (written < nsl) {
                 while (issued < nsl && issued < written + R_OUT - 1) {
@@ -399,15 +473,38 @@ static void *writer_main(void *arg)
                 written++;
             }
             oslice += nsl;
-            if (nsl == 0) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->down_ev[b]), "event record", c);
-        } else CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->down_ev[b]), "event record", c);
+        }
+        p->out_off += out_bytes;
         pthread_mutex_lock(&p->mu);
         p->n_down = k + 1;
         pthread_cond_broadcast(&p->cv);
         pthread_mutex_unlock(&p->mu);
         if (bt.last) break;
     }
+    if (par) {
+        pthread_mutex_lock(&p->wmu);
+        p->wq_done = 1;
+        pthread_cond_broadcast(&p->wcv);
+        pthread_mutex_unlock(&p->wmu);
+        for (int i = 0; i < NWRITERS; i++) pthread_join(pw[i], NULL);
+        pthread_mutex_destroy(&p->wmu);
+        pthread_cond_destroy(&p->wcv);
+    }
     return NULL;
+}
+
+/* a seekable output: flush what the caller (or the header write) has buffered and continue with pwrite() at absolute
+ * offsets; -1 = not seekable, keep to fwrite */
+static int output_fd(FILE *fout, uint64_t *off)
+{
+    if (isTestThroughput == 1 || getenv("MRCZ_NO_PWRITE")) return -1;
+    if (fflush(fout) != 0) return -1;
+    const int fd = fileno(fout);
+    if (fd < 0) return -1;
+    const off_t at = lseek(fd, 0, SEEK_CUR);
+    if (at < 0) return -1;
+    *off = (uint64_t)at;
+    return fd;
 }
 
 /* the caller's thread: enqueue the codec for every batch the reader hands over */
@@ -484,8 +581,10 @@ int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const 
     pipe_t p;
     memset(&p, 0, sizeof(p));
     p.s = ses; p.c = ses->e->c; p.fin = fin; p.fout = fout; p.decode = 0; p.int_mode = int_mode; p.bits = bitsToMask; p.chk = CHUNK_SIZE; p.total_floats = file_floats; p.batch_chunks = batch;
+    p.fd_out = output_fd(fout, &p.out_off);
     p.t_setup = now_sec() - begin;
     run_pipeline(&p);
+    if (p.fd_out >= 0) fseeko(fout, (off_t)p.out_off, SEEK_SET); /* the stream continues after what pwrite() wrote */
     const double elapsed = now_sec() - begin;
     trace_report(&p, "run_compress", elapsed, file_floats * 4);
     ctx->zipTime += elapsed;
@@ -522,8 +621,10 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
     pipe_t p;
     memset(&p, 0, sizeof(p));
     p.s = ses; p.c = ses->e->c; p.fin = fin; p.fout = fout; p.decode = 1; p.int_mode = int_mode; p.chk = chk; p.total_floats = nfloats; p.batch_chunks = batch;
+    p.fd_out = output_fd(fout, &p.out_off);
     p.t_setup = now_sec() - begin;
     run_pipeline(&p);
+    if (p.fd_out >= 0) fseeko(fout, (off_t)p.out_off, SEEK_SET);
     const double elapsed = now_sec() - begin;
     trace_report(&p, "run_uncompress", elapsed, nfloats * 4);
     ctx->unzipTime += elapsed;
