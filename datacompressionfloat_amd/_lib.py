@@ -57,5 +57,5 @@ EXPORTS = [
     "mrcz_host_malloc", "mrcz_host_free", "mrcz_copy_h2d", "mrcz_copy_d2h",
     "mrcz_event_create", "mrcz_event_destroy", "mrcz_event_record", "mrcz_stream_wait_event", "mrcz_event_sync",
     "mrcz_copy_h2d_async", "mrcz_copy_d2h_async", "mrcz_compress_chunks_async", "mrcz_uncompress_chunks_async",
-    "mrcz_generate_kat_words", "mrcz_compress_chunks_int8", "mrcz_uncompress_chunks_int8", "mrcz_compress_chunks_int8_async", "mrcz_uncompress_chunks_int8_async",
+    "mrcz_generate_kat_words", "mrcz_err_hist", "mrcz_err_collect", "mrcz_compress_chunks_int8", "mrcz_uncompress_chunks_int8", "mrcz_compress_chunks_int8_async", "mrcz_uncompress_chunks_int8_async",
 ]

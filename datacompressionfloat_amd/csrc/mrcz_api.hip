@@ -11,6 +11,7 @@
 #include "mrcz_huffman.hip"
 #include "mrcz_inflate.hip"
 #include "mrcz_inflate_par.hip"
+#include "mrcz_tools.hip"
 
 #include "../../include/mrcz_hip.h"
 
@@ -76,6 +77,7 @@ struct mrcz_ctx {
     uint32_t blk_grid;     /* workgroups of the persistent block decoder */
     unsigned long long *dbgphase; /* 8 counters per stream when phase profiling is on */
     int phase_profile;
+    unsigned long long *errhist; /* erroranalysis: 2048 histogram bins + the candidate counter; allocated on first use */
     uint8_t *planes;       /* byte planes of one batch (stream s at s * CHK), both directions; allocated on first use */
     /* timing */
     int timing;
@@ -216,6 +218,7 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->segs); (void)hipFree(ctx->nseg); (void)hipFree(ctx->segidx); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->scratch); (void)hipFree(ctx->hdrs); (void)hipFree(ctx->njobs);
     (void)hipFree(ctx->dbgphase);
     (void)hipFree(ctx->planes);
+    (void)hipFree(ctx->errhist);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -715,6 +718,59 @@ extern "C" int mrcz_generate_kat_words(mrcz_ctx_t *ctx, void *d_words, uint64_t 
     hipStream_t lstream = ctx->stream;
     LAUNCH("k_generate_kat", k_generate_kat, dim3(4096), dim3(256), (uint32_t *)d_words, first_index, nwords);
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (generate)");
+    return MRCZ_OK;
+}
+
+/* ---- erroranalysis on the device (include/mrcz_hip.h; src/tool/erroranalysis.c) ---- */
+extern "C" int mrcz_err_hist(mrcz_ctx_t *ctx, const void *d_orig, const void *d_dec, uint64_t n, int pass, uint32_t prefix, int reset,
+                             uint64_t hist[2048])
+{
+    if (!ctx || pass < 0 || pass > 2) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->ntimers = 0;
+    hipStream_t lstream = ctx->stream;
+    if (!ctx->errhist) {
+        hipError_t e = hipMalloc((void **)&ctx->errhist, 2049 * sizeof(unsigned long long));
+        if (e != hipSuccess) { ctx->errhist = NULL; return fail(ctx, MRCZ_ENOMEM, "error histogram", e); }
+        reset = 1;
+    }
+    if (reset) HIPCHK(hipMemsetAsync(ctx->errhist, 0, 2049 * sizeof(unsigned long long), ctx->stream), "memset");
+    /* key bits: pass 0 = 31..21 (11 bits), pass 1 = 20..10 (11 bits, points whose bits 31..21 == prefix), pass 2 = 9..0 (10 bits,
+     * points whose bits 31..10 == prefix) */
+    const uint32_t shift = pass == 0 ? 21u : pass == 1 ? 10u : 0u, nbits = pass == 2 ? 10u : 11u;
+    const uint32_t pshift = pass == 0 ? 32u : pass == 1 ? 21u : 10u;
+    if (n) {
+        if (!d_orig || !d_dec) return MRCZ_EINVAL;
+        LAUNCH("k_err_hist", k_err_hist, dim3(2048), dim3(256), (const uint32_t *)d_orig, (const uint32_t *)d_dec, n, shift, nbits, pshift, prefix,
+               ctx->errhist);
+    }
+    if (hist) {
+        HIPCHK(hipMemcpyAsync(hist, ctx->errhist, 2048 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream), "copy hist");
+        HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (hist)");
+    }
+    return MRCZ_OK;
+}
+
+extern "C" int mrcz_err_collect(mrcz_ctx_t *ctx, const void *d_orig, const void *d_dec, uint64_t n, uint64_t base_index, uint32_t threshold_bits,
+                                void *d_points, uint64_t cap_points, uint64_t count_in, uint64_t *count_out)
+{
+    if (!ctx || !d_orig || !d_dec || !d_points || !count_out) return MRCZ_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->ntimers = 0;
+    hipStream_t lstream = ctx->stream;
+    if (!ctx->errhist) {
+        hipError_t e = hipMalloc((void **)&ctx->errhist, 2049 * sizeof(unsigned long long));
+        if (e != hipSuccess) { ctx->errhist = NULL; return fail(ctx, MRCZ_ENOMEM, "error histogram", e); }
+    }
+    unsigned long long *cnt = ctx->errhist + 2048;
+    unsigned long long start = count_in;
+    HIPCHK(hipMemcpyAsync(cnt, &start, sizeof(start), hipMemcpyHostToDevice, ctx->stream), "copy count");
+    if (n) LAUNCH("k_err_collect", k_err_collect, dim3(2048), dim3(256), (const uint32_t *)d_orig, (const uint32_t *)d_dec, n, base_index, threshold_bits,
+                  (ErrPoint *)d_points, cnt, cap_points);
+    unsigned long long got = 0;
+    HIPCHK(hipMemcpyAsync(&got, cnt, sizeof(got), hipMemcpyDeviceToHost, ctx->stream), "copy count");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (collect)");
+    *count_out = got;
     return MRCZ_OK;
 }
 

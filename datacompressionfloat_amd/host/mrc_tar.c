@@ -3,6 +3,7 @@
  * (/root/reference/src/main/mrc_tar.c:82-165): mrc_tar -i <in> -o <out> [-t zip|unzip] [-b 0..32]
  * [-s float|int] [-h].  The work is done by run_compress / run_uncompress on the GPU.
  */
+#include "../../include/mrcz_hip.h"
 #include "../../include/mrcz_workers.h"
 
 #include <stdlib.h>
@@ -17,27 +18,35 @@ static void usage(char **argv) /* mrc_tar.c:82-100 */
     printf("\t-b\t bits to be erased, range[0..32], default is 0\n\n");
     printf("\t-s\t data type to be converted to when compressed/decompressed, value should be [float | int], default is float\n\n");
     printf("\t-t\t operation type, e.g compress or decompressed file, value should be [zip | unzip], default is zip\n\n");
-    printf("\t-g\t HIP device to use, default 0 (extension of the MI355X build)\n\n");
+    printf("\t-g\t first HIP device to use, default 0 (extension of the MI355X build)\n\n");
+    printf("\t-G\t number of HIP devices the file's chunks are dealt to, default: all visible devices (extension of the MI355X build)\n\n");
 }
 
 int main(int argc, char *argv[])
 {
     const char *in = NULL, *out = NULL, *op = "zip", *dtype = "float";
-    int bits = 0, opt;
+    int bits = 0, opt, dev0 = 0, ndev = 0;
     if (argc < 2) { usage(argv); exit(-1); }
-    while ((opt = getopt(argc, argv, "hi:o:b:t:s:g:")) != -1) {
+    while ((opt = getopt(argc, argv, "hi:o:b:t:s:g:G:")) != -1) {
         switch (opt) {
         case 'i': in = optarg; break;
         case 'o': out = optarg; break;
         case 'b': bits = atoi(optarg); break;
         case 't': op = optarg; break;
         case 's': dtype = optarg; break;
-        case 'g': mrcz_workers_set_device(atoi(optarg)); break;
+        case 'g': dev0 = atoi(optarg); break;
+        case 'G': ndev = atoi(optarg); break;
         case 'h': usage(argv); return 0;
         default: printf("Invalid command line parameters!\n"); usage(argv); return -1;
         }
     }
     if (!in || !out) { usage(argv); return -1; }
+    {   /* one file: its chunks are dealt over the GPUs of the node; -g / -G narrow that */
+        const int have = mrcz_device_count();
+        if (ndev <= 0) ndev = have - dev0;
+        if (ndev < 1) ndev = 1;
+        mrcz_workers_set_devices(dev0, ndev);
+    }
     printf("CODEC:mrcz-hip gfx950 (DEFLATE Z_RLE stream-compatible with ZLIB:1.2.8)\n"); /* mrc_tar.c:152 prints the zlib version */
     ctx_t ctx;
     init_context(&ctx);

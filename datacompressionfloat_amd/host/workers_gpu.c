@@ -41,10 +41,19 @@ int isTestThroughput = 0; /* src/core/workers.c:39 */
 #define CHUNK_BYTES ((uint64_t)CHUNK_SIZE * 4u)
 #define IN_SLOT (CHUNK_BYTES + 64u) /* a chunk of floats, or a chunk record (16-byte header + <= 4 RAW planes) */
 
-static __thread int t_device = 0;
+#define MAXND 16                  /* devices one call may deal its batches to */
+static __thread int t_device = 0; /* first (logical) device of the calling thread */
+static __thread int t_ndev = 1;   /* devices the thread's calls deal their batches to: t_device .. t_device + t_ndev - 1 */
 static int g_batch_chunks = 8; /* chunks per device batch: 192 MiB of floats */
 
-void mrcz_workers_set_device(int device) { t_device = device; }
+void mrcz_workers_set_device(int device) { t_device = device; t_ndev = 1; }
+/* the chunks of ONE file dealt over several GPUs.  Batch k of a call goes to device first + k % ndevices; every
+ * device codes its batches independently (chunks are independent streams), the writer emits the records in file order. */
+void mrcz_workers_set_devices(int first, int ndevices)
+{
+    t_device = first < 0 ? 0 : first;
+    t_ndev = ndevices < 1 ? 1 : (ndevices > MAXND ? MAXND : ndevices);
+}
 void mrcz_workers_set_batch_chunks(int chunks) { g_batch_chunks = chunks < 1 ? 1 : (chunks > 128 ? 128 : chunks); }
 static int batch_chunks(void) /* MRCZ_BATCH_CHUNKS overrides the default (tests: several batches from small files) */
 {
@@ -101,6 +110,14 @@ typedef struct {
 static engine_t g_eng[MAXDEV];
 static pthread_mutex_t g_eng_mu = PTHREAD_MUTEX_INITIALIZER;
 
+/* MRCZ_DEVICE_ALIAS=1 folds logical devices onto the physical ones (logical d -> d mod count): several engines on one GPU, to
+ * rehearse the multi-device path where only one is present */
+static int physical_device(int logical)
+{
+    if (getenv("MRCZ_DEVICE_ALIAS")) { const int n = mrcz_device_count(); return n > 0 ? logical % n : logical; }
+    return logical;
+}
+
 static engine_t *engine_get(int device)
 {
     if (device < 0 || device >= MAXDEV) die("device index out of range", NULL);
@@ -109,7 +126,7 @@ static engine_t *engine_get(int device)
     pthread_mutex_lock(&g_eng_mu);
     if (!e->c) {
         e->batch = batch_chunks();
-        if (mrcz_create(&e->c, device, (uint32_t)e->batch) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
+        if (mrcz_create(&e->c, physical_device(device), (uint32_t)e->batch) != MRCZ_OK) die("no usable HIP device (the codec has no CPU path)", NULL);
         pthread_mutex_init(&e->mu, NULL);
     }
     pthread_mutex_unlock(&g_eng_mu);
@@ -119,16 +136,20 @@ static engine_t *engine_get(int device)
 /* ---- per-thread session: pinned rings, device batch buffers, events; kept between calls ----
  * The reference's worker threads call run_compress / run_uncompress once per file (adapt.c:28-90); pinning host
  * memory costs ~0.2 s per GiB, so a thread keeps its (small, chunk-granular) rings until it exits. */
-typedef struct {
+typedef struct {                     /* what a session holds on one device */
     engine_t *e;
-    int device;
-    void *h_in[R_IN], *h_out[R_OUT];
-    uint64_t *h_res[2];              /* pinned result words of the two batches in flight */
+    uint64_t *h_res[2];              /* pinned result words of the two batches in flight on this device */
     void *d_a[2], *d_b[2];           /* device: batch input [2], batch output [2] */
     uint64_t d_a_cap, d_b_cap;
-    mrcz_event_t *in_ev[R_IN];       /* upload of ring slot i is done */
-    mrcz_event_t *out_ev[R_OUT];     /* download into ring slot i is done */
+    mrcz_event_t *in_ev[R_IN];       /* upload of ring slot i (to this device) is done */
+    mrcz_event_t *out_ev[R_OUT];     /* download into ring slot i (from this device) is done */
     mrcz_event_t *up_ev[2], *comp_ev[2], *down_ev[2]; /* batch buffer b: uploaded / coded / downloaded */
+} devses_t;
+typedef struct {
+    int dev0, ndev;                  /* logical devices the session was built for (0 = not built) */
+    devses_t d[MAXND];
+    void *h_in[R_IN], *h_out[R_OUT]; /* pinned rings, shared by the devices */
+    int in_dev[R_IN], out_dev[R_OUT];/* device (index into d[]) that used the slot last */
 } session_t;
 static __thread session_t t_s;
 static pthread_key_t s_key;
@@ -137,48 +158,70 @@ static pthread_once_t s_once = PTHREAD_ONCE_INIT;
 static void session_release(void *p)
 {
     session_t *s = (session_t *)p;
-    if (!s || !s->e) return;
-    mrcz_ctx_t *c = s->e->c;
-    for (int i = 0; i < R_IN; i++) { if (s->h_in[i]) mrcz_host_free(c, s->h_in[i]); mrcz_event_destroy(c, s->in_ev[i]); }
-    for (int i = 0; i < R_OUT; i++) { if (s->h_out[i]) mrcz_host_free(c, s->h_out[i]); mrcz_event_destroy(c, s->out_ev[i]); }
-    for (int b = 0; b < 2; b++) {
-        mrcz_host_free(c, s->h_res[b]);
-        mrcz_dev_free(c, s->d_a[b]); mrcz_dev_free(c, s->d_b[b]);
-        mrcz_event_destroy(c, s->up_ev[b]); mrcz_event_destroy(c, s->comp_ev[b]); mrcz_event_destroy(c, s->down_ev[b]);
+    if (!s || !s->ndev) return;
+    mrcz_ctx_t *c0 = s->d[0].e->c;
+    for (int i = 0; i < R_IN; i++) if (s->h_in[i]) mrcz_host_free(c0, s->h_in[i]);
+    for (int i = 0; i < R_OUT; i++) if (s->h_out[i]) mrcz_host_free(c0, s->h_out[i]);
+    for (int di = 0; di < s->ndev; di++) {
+        devses_t *D = &s->d[di];
+        mrcz_ctx_t *c = D->e->c;
+        for (int i = 0; i < R_IN; i++) mrcz_event_destroy(c, D->in_ev[i]);
+        for (int i = 0; i < R_OUT; i++) mrcz_event_destroy(c, D->out_ev[i]);
+        for (int b = 0; b < 2; b++) {
+            mrcz_host_free(c, D->h_res[b]);
+            mrcz_dev_free(c, D->d_a[b]); mrcz_dev_free(c, D->d_b[b]);
+            mrcz_event_destroy(c, D->up_ev[b]); mrcz_event_destroy(c, D->comp_ev[b]); mrcz_event_destroy(c, D->down_ev[b]);
+        }
     }
     memset(s, 0, sizeof(*s));
 }
 static void session_key_init(void) { pthread_key_create(&s_key, session_release); }
 
-/* rings and events once; device batch buffers sized for `a_bytes` in, `b_bytes` out (they only grow) */
-static session_t *session_get(uint64_t a_bytes, uint64_t b_bytes)
+/* devices a thread's calls may deal their batches to (MRCZ_DEVICES overrides what the front-end asked for: tests) */
+static int thread_ndev(void)
+{
+    const char *e = getenv("MRCZ_DEVICES");
+    int n = (e && atoi(e) > 0) ? atoi(e) : t_ndev;
+    return n > MAXND ? MAXND : n;
+}
+
+/* The session of the calling thread with its first `nd` devices ready: events once per device; device batch buffers sized
+ * for `a_bytes` in, `b_bytes` out (they only grow); the ring slots themselves are pinned on first use (reader: h_in, writer:
+ * h_out): a small file touches one of each, and only as many devices are set up as the file has batches. */
+static session_t *session_get(uint64_t a_bytes, uint64_t b_bytes, int nd)
 {
     pthread_once(&s_once, session_key_init);
     session_t *s = &t_s;
-    if (s->e && s->device != t_device) session_release(s);
-    if (!s->e) {
-        s->e = engine_get(t_device);
-        s->device = t_device;
-        mrcz_ctx_t *c = s->e->c;
-        /* the ring slots themselves are pinned on first use (reader: h_in, writer: h_out): a small file touches one of each */
-        for (int i = 0; i < R_IN; i++) CK(mrcz_event_create(c, &s->in_ev[i]), "event", c);
-        for (int i = 0; i < R_OUT; i++) CK(mrcz_event_create(c, &s->out_ev[i]), "event", c);
-        for (int b = 0; b < 2; b++) {
-            CK(mrcz_host_malloc(c, (void **)&s->h_res[b], 64), "fail to alloc mem", c);
-            CK(mrcz_event_create(c, &s->up_ev[b]), "event", c);
-            CK(mrcz_event_create(c, &s->comp_ev[b]), "event", c);
-            CK(mrcz_event_create(c, &s->down_ev[b]), "event", c);
-        }
+    if (s->ndev && s->dev0 != t_device) session_release(s);
+    if (!s->ndev) {
+        s->dev0 = t_device;
         pthread_setspecific(s_key, s); /* released when the thread exits */
     }
-    mrcz_ctx_t *c = s->e->c;
-    if (s->d_a_cap < a_bytes) {
-        for (int b = 0; b < 2; b++) { if (s->d_a[b]) mrcz_dev_free(c, s->d_a[b]); CK(mrcz_dev_malloc(c, &s->d_a[b], a_bytes), "fail to alloc mem", c); }
-        s->d_a_cap = a_bytes;
+    for (int di = s->ndev; di < nd; di++) {
+        devses_t *D = &s->d[di];
+        D->e = engine_get(t_device + di);
+        mrcz_ctx_t *c = D->e->c;
+        for (int i = 0; i < R_IN; i++) CK(mrcz_event_create(c, &D->in_ev[i]), "event", c);
+        for (int i = 0; i < R_OUT; i++) CK(mrcz_event_create(c, &D->out_ev[i]), "event", c);
+        for (int b = 0; b < 2; b++) {
+            CK(mrcz_host_malloc(c, (void **)&D->h_res[b], 64), "fail to alloc mem", c);
+            CK(mrcz_event_create(c, &D->up_ev[b]), "event", c);
+            CK(mrcz_event_create(c, &D->comp_ev[b]), "event", c);
+            CK(mrcz_event_create(c, &D->down_ev[b]), "event", c);
+        }
+        s->ndev = di + 1;
     }
-    if (s->d_b_cap < b_bytes) {
-        for (int b = 0; b < 2; b++) { if (s->d_b[b]) mrcz_dev_free(c, s->d_b[b]); CK(mrcz_dev_malloc(c, &s->d_b[b], b_bytes), "fail to alloc mem", c); }
-        s->d_b_cap = b_bytes;
+    for (int di = 0; di < nd; di++) {
+        devses_t *D = &s->d[di];
+        mrcz_ctx_t *c = D->e->c;
+        if (D->d_a_cap < a_bytes) {
+            for (int b = 0; b < 2; b++) { if (D->d_a[b]) mrcz_dev_free(c, D->d_a[b]); CK(mrcz_dev_malloc(c, &D->d_a[b], a_bytes), "fail to alloc mem", c); }
+            D->d_a_cap = a_bytes;
+        }
+        if (D->d_b_cap < b_bytes) {
+            for (int b = 0; b < 2; b++) { if (D->d_b[b]) mrcz_dev_free(c, D->d_b[b]); CK(mrcz_dev_malloc(c, &D->d_b[b], b_bytes), "fail to alloc mem", c); }
+            D->d_b_cap = b_bytes;
+        }
     }
     return s;
 }
@@ -193,7 +236,7 @@ typedef struct {
 
 typedef struct {
     session_t *s;
-    mrcz_ctx_t *c;
+    int nd;               /* devices the batches are dealt to: batch k -> device k % nd, buffer (k / nd) & 1 */
     FILE *fin, *fout;
     int decode;           /* 0 = run_compress, 1 = run_uncompress */
     int int_mode;         /* dataConvertedType == "int" (workers.c:782-787, 604-609) */
@@ -201,10 +244,10 @@ typedef struct {
     uint32_t chk;         /* floats per chunk */
     uint64_t total_floats;/* decode: floats of the file */
     int batch_chunks;
-    /* queues (one slot per batch buffer is enough: at most two batches are in flight) */
+    /* queues (one slot per batch buffer is enough: at most two batches are in flight per device) */
     pthread_mutex_t mu;
     pthread_cond_t cv;
-    batch_t q_up[2], q_done[2];
+    batch_t q_up[2 * MAXND], q_done[2 * MAXND];
     uint64_t n_read;      /* batches the reader has handed over */
     uint64_t n_enq;       /* batches whose kernels are enqueued (comp_ev recorded) */
     uint64_t n_down;      /* batches fully downloaded / written (down_ev recorded) */
@@ -256,19 +299,21 @@ static void *reader_main(void *arg)
 {
     pipe_t *p = (pipe_t *)arg;
     session_t *s = p->s;
-    mrcz_ctx_t *c = p->c;
+    const uint64_t nd = (uint64_t)p->nd, inflight = 2u * nd;
     uint64_t chunk = 0, k = 0, done_floats = 0;
     uint64_t mpos = 0, msize = 0;
     const unsigned char *map = map_input(p->fin, &mpos, &msize);
     int eof = 0;
     while (!eof) {
-        const int b = (int)(k & 1u);
-        /* batch buffer b is free once batch k-2 has been coded: wait until its kernels are at least enqueued, then let the
-         * upload stream wait for them on the device */
+        const int di = (int)(k % nd), b = (int)((k / nd) & 1u), qi = 2 * di + b;
+        devses_t *D = &s->d[di];
+        mrcz_ctx_t *c = D->e->c;
+        /* batch buffer (device di, b) is free once batch k - 2 nd has been coded: wait until its kernels are at least enqueued,
+         * then let the device's upload stream wait for them on the device */
         pthread_mutex_lock(&p->mu);
-        while (k >= 2 && p->n_enq < k - 1) pthread_cond_wait(&p->cv, &p->mu);
+        while (k >= inflight && p->n_enq < k - inflight + 1) pthread_cond_wait(&p->cv, &p->mu);
         pthread_mutex_unlock(&p->mu);
-        if (k >= 2) CK(mrcz_stream_wait_event(c, MRCZ_STREAM_UPLOAD, s->comp_ev[b]), "stream wait", c);
+        if (k >= inflight) CK(mrcz_stream_wait_event(c, MRCZ_STREAM_UPLOAD, D->comp_ev[b]), "stream wait", c);
         batch_t bt;
         memset(&bt, 0, sizeof(bt));
         bt.first_chunk = chunk;
@@ -283,7 +328,10 @@ static void *reader_main(void *arg)
             double tt = now_sec();
             if (!map) {
                 slot = (int)(chunk % R_IN);
-                if (chunk >= R_IN) CK(mrcz_event_sync(c, s->in_ev[slot]), "event sync", c); /* the slot's previous upload is done */
+                if (chunk >= R_IN) { /* the slot's previous upload (possibly to another device) is done */
+                    devses_t *P = &s->d[s->in_dev[slot]];
+                    CK(mrcz_event_sync(P->e->c, P->in_ev[slot]), "event sync", P->e->c);
+                }
                 p->t_slotwait += now_sec() - tt;
                 tt = now_sec();
                 if (!s->h_in[slot]) CK(mrcz_host_malloc(c, &s->h_in[slot], IN_SLOT), "fail to alloc mem", c);
@@ -330,18 +378,18 @@ static void *reader_main(void *arg)
             mpos += bytes;
             if (done_floats >= p->total_floats) eof = 1;
             if (!map) p->t_fread += now_sec() - tt;
-            CK(mrcz_copy_h2d_async(c, MRCZ_STREAM_UPLOAD, (char *)s->d_a[b] + off, h, bytes), "H2D copy", c);
+            CK(mrcz_copy_h2d_async(c, MRCZ_STREAM_UPLOAD, (char *)D->d_a[b] + off, h, bytes), "H2D copy", c);
             if (map) p->t_fread += now_sec() - tt; /* a copy from pageable memory returns when the source has been consumed */
-            else CK(mrcz_event_record(c, MRCZ_STREAM_UPLOAD, s->in_ev[slot]), "event record", c);
+            else { CK(mrcz_event_record(c, MRCZ_STREAM_UPLOAD, D->in_ev[slot]), "event record", c); s->in_dev[slot] = di; }
             off += bytes;
             chunk++;
         }
         if (bt.units == 0) break;
         bt.in_bytes = off;
         bt.last = eof;
-        CK(mrcz_event_record(c, MRCZ_STREAM_UPLOAD, s->up_ev[b]), "event record", c);
+        CK(mrcz_event_record(c, MRCZ_STREAM_UPLOAD, D->up_ev[b]), "event record", c);
         pthread_mutex_lock(&p->mu);
-        p->q_up[b] = bt;
+        p->q_up[qi] = bt;
         p->n_read = k + 1;
         pthread_cond_broadcast(&p->cv);
         pthread_mutex_unlock(&p->mu);
@@ -350,8 +398,11 @@ static void *reader_main(void *arg)
     if (map) {
         /* the mapping may only go away once every copy out of it is done (a copy from pageable memory is normally complete when
          * the call returns; the event makes it certain) */
-        CK(mrcz_event_record(c, MRCZ_STREAM_UPLOAD, s->in_ev[0]), "event record", c);
-        CK(mrcz_event_sync(c, s->in_ev[0]), "event sync", c);
+        for (int di = 0; di < p->nd; di++) {
+            devses_t *D = &s->d[di];
+            CK(mrcz_event_record(D->e->c, MRCZ_STREAM_UPLOAD, D->in_ev[0]), "event record", D->e->c);
+            CK(mrcz_event_sync(D->e->c, D->in_ev[0]), "event sync", D->e->c);
+        }
         munmap((void *)map, (size_t)msize);
         if (p->decode) fseek(p->fin, (long)mpos, SEEK_SET); /* leave the stream where fread would have left it */
     }
@@ -375,7 +426,10 @@ static void *pwrite_main(void *arg)
         const uint64_t off = p->wq[i].off, len = p->wq[i].len;
         p->wq_head++;
         pthread_mutex_unlock(&p->wmu);
-        CK(mrcz_event_sync(p->c, s->out_ev[slot]), "event sync", p->c);
+        {
+            devses_t *D = &s->d[s->out_dev[slot]]; /* (set before the slice was queued, under wmu) */
+            CK(mrcz_event_sync(D->e->c, D->out_ev[slot]), "event sync", D->e->c);
+        }
         uint64_t done = 0;
         while (done < len) {
             const ssize_t w = pwrite(p->fd_out, (const char *)s->h_out[slot] + done, (size_t)(len - done), (off_t)(off + done));
@@ -394,7 +448,7 @@ static void *writer_main(void *arg)
 {
     pipe_t *p = (pipe_t *)arg;
     session_t *s = p->s;
-    mrcz_ctx_t *c = p->c;
+    const uint64_t nd = (uint64_t)p->nd;
     uint64_t oslice = 0; /* output ring position */
     pthread_t pw[NWRITERS];
     const int par = p->fd_out >= 0 && isTestThroughput != 1;
@@ -405,26 +459,28 @@ static void *writer_main(void *arg)
             if (pthread_create(&pw[i], NULL, pwrite_main, p) != 0) die("pthread_create", NULL);
     }
     for (uint64_t k = 0;; k++) {
-        const int b = (int)(k & 1u);
+        const int di = (int)(k % nd), b = (int)((k / nd) & 1u), qi = 2 * di + b;
+        devses_t *D = &s->d[di];
+        mrcz_ctx_t *c = D->e->c;
         pthread_mutex_lock(&p->mu);
         while (p->n_enq <= k && !(p->reader_eof && p->n_read <= k)) pthread_cond_wait(&p->cv, &p->mu);
         const int have = p->n_enq > k;
-        const batch_t bt = p->q_done[b];
+        const batch_t bt = p->q_done[qi];
         pthread_mutex_unlock(&p->mu);
         if (!have) break;
         const double t0 = now_sec();
-        CK(mrcz_event_sync(c, s->comp_ev[b]), "event sync", c);
+        CK(mrcz_event_sync(c, D->comp_ev[b]), "event sync", c);
         p->gpu_time += now_sec() - t0;
         uint64_t out_bytes;
         if (!p->decode) {
-            out_bytes = s->h_res[b][0];
-            for (int j = 0; j < 4; j++) p->plane_z[j] += s->h_res[b][1 + j];
+            out_bytes = D->h_res[b][0];
+            for (int j = 0; j < 4; j++) p->plane_z[j] += D->h_res[b][1 + j];
         } else {
-            if (s->h_res[b][1] != 0 || s->h_res[b][0] != bt.in_bytes) die("uncompress: malformed chunk records or deflate stream", NULL);
+            if (D->h_res[b][1] != 0 || D->h_res[b][0] != bt.in_bytes) die("uncompress: malformed chunk records or deflate stream", NULL);
             out_bytes = bt.units * 4u;
         }
         const uint64_t nsl = (out_bytes + OUT_SLOT - 1) / OUT_SLOT;
-        if (isTestThroughput == 1 || nsl == 0) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->down_ev[b]), "event record", c);
+        if (isTestThroughput == 1 || nsl == 0) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, D->down_ev[b]), "event record", c);
         else if (par) {
             /* every slice: wait for a free ring slot, start its copy, hand it to the pwrite threads */
             for (uint64_t j = 0; j < nsl; j++) {
@@ -437,10 +493,11 @@ static void *writer_main(void *arg)
                 p->t_fwrite += now_sec() - tt;
                 if (!s->h_out[os]) CK(mrcz_host_malloc(c, &s->h_out[os], OUT_SLOT), "fail to alloc mem", c);
                 const uint64_t o = j * OUT_SLOT, l = (out_bytes - o) < OUT_SLOT ? (out_bytes - o) : OUT_SLOT;
-                CK(mrcz_copy_d2h_async(c, MRCZ_STREAM_DOWNLOAD, s->h_out[os], (char *)s->d_b[b] + o, l), "D2H copy", c);
-                CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->out_ev[os]), "event record", c);
-                if (j + 1 == nsl) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->down_ev[b]), "event record", c);
+                CK(mrcz_copy_d2h_async(c, MRCZ_STREAM_DOWNLOAD, s->h_out[os], (char *)D->d_b[b] + o, l), "D2H copy", c);
+                CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, D->out_ev[os]), "event record", c);
+                if (j + 1 == nsl) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, D->down_ev[b]), "event record", c);
                 pthread_mutex_lock(&p->wmu);
+                s->out_dev[os] = di;
                 const int i = p->wq_tail % R_OUT;
                 p->wq[i].slot = os; p->wq[i].off = p->out_off + o; p->wq[i].len = l;
                 p->wq_tail++;
@@ -457,15 +514,15 @@ static void *writer_main(void *arg)
                     const int os = (int)((oslice + issued) % R_OUT);
                     if (!s->h_out[os]) CK(mrcz_host_malloc(c, &s->h_out[os], OUT_SLOT), "fail to alloc mem", c);
                     const uint64_t o = issued * OUT_SLOT, l = (out_bytes - o) < OUT_SLOT ? (out_bytes - o) : OUT_SLOT;
-                    CK(mrcz_copy_d2h_async(c, MRCZ_STREAM_DOWNLOAD, s->h_out[os], (char *)s->d_b[b] + o, l), "D2H copy", c);
-                    CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->out_ev[os]), "event record", c);
+                    CK(mrcz_copy_d2h_async(c, MRCZ_STREAM_DOWNLOAD, s->h_out[os], (char *)D->d_b[b] + o, l), "D2H copy", c);
+                    CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, D->out_ev[os]), "event record", c);
                     issued++;
-                    if (issued == nsl) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, s->down_ev[b]), "event record", c);
+                    if (issued == nsl) CK(mrcz_event_record(c, MRCZ_STREAM_DOWNLOAD, D->down_ev[b]), "event record", c);
                 }
                 const int os = (int)((oslice + written) % R_OUT);
                 const uint64_t o = written * OUT_SLOT, l = (out_bytes - o) < OUT_SLOT ? (out_bytes - o) : OUT_SLOT;
                 double tt = now_sec();
-                CK(mrcz_event_sync(c, s->out_ev[os]), "event sync", c);
+                CK(mrcz_event_sync(c, D->out_ev[os]), "event sync", c);
                 p->t_d2hwait += now_sec() - tt;
                 tt = now_sec();
                 if (fwrite(s->h_out[os], 1, (size_t)l, p->fout) != l) die("fwrite", NULL); /* workers.c:837-850 / 627,668 */
@@ -511,37 +568,39 @@ static int output_fd(FILE *fout, uint64_t *off)
 static void run_pipeline(pipe_t *p)
 {
     session_t *s = p->s;
-    mrcz_ctx_t *c = p->c;
+    const uint64_t nd = (uint64_t)p->nd, inflight = 2u * nd;
     pthread_mutex_init(&p->mu, NULL);
     pthread_cond_init(&p->cv, NULL);
     pthread_t rd, wr;
     if (pthread_create(&rd, NULL, reader_main, p) != 0 || pthread_create(&wr, NULL, writer_main, p) != 0) die("pthread_create", NULL);
     const uint64_t rec_cap = mrcz_records_bound((uint64_t)p->batch_chunks * CHUNK_SIZE) + 64;
     for (uint64_t k = 0;; k++) {
-        const int b = (int)(k & 1u);
+        const int di = (int)(k % nd), b = (int)((k / nd) & 1u), qi = 2 * di + b;
+        devses_t *D = &s->d[di];
+        mrcz_ctx_t *c = D->e->c;
         pthread_mutex_lock(&p->mu);
         while (p->n_read <= k && !p->reader_eof) pthread_cond_wait(&p->cv, &p->mu);
         const int have = p->n_read > k;
-        const batch_t bt = p->q_up[b];
-        /* output buffer b and result words b are free once batch k-2 has been downloaded */
-        while (have && k >= 2 && p->n_down < k - 1) pthread_cond_wait(&p->cv, &p->mu);
+        const batch_t bt = p->q_up[qi];
+        /* output buffer (di, b) and its result words are free once batch k - 2 nd has been downloaded */
+        while (have && k >= inflight && p->n_down < k - inflight + 1) pthread_cond_wait(&p->cv, &p->mu);
         pthread_mutex_unlock(&p->mu);
         if (!have) break;
-        pthread_mutex_lock(&s->e->mu);
-        CK(mrcz_stream_wait_event(c, MRCZ_STREAM_COMPUTE, s->up_ev[b]), "stream wait", c);
-        if (k >= 2) CK(mrcz_stream_wait_event(c, MRCZ_STREAM_COMPUTE, s->down_ev[b]), "stream wait", c);
+        pthread_mutex_lock(&D->e->mu);
+        CK(mrcz_stream_wait_event(c, MRCZ_STREAM_COMPUTE, D->up_ev[b]), "stream wait", c);
+        if (k >= inflight) CK(mrcz_stream_wait_event(c, MRCZ_STREAM_COMPUTE, D->down_ev[b]), "stream wait", c);
         if (!p->decode && !p->int_mode)
-            CK(mrcz_compress_chunks_async(c, s->d_a[b], bt.units, bt.first_chunk, p->bits, s->d_b[b], rec_cap, s->h_res[b]), "compress", c);
+            CK(mrcz_compress_chunks_async(c, D->d_a[b], bt.units, bt.first_chunk, p->bits, D->d_b[b], rec_cap, D->h_res[b]), "compress", c);
         else if (!p->decode)
-            CK(mrcz_compress_chunks_int8_async(c, s->d_a[b], bt.units, bt.first_chunk, s->d_b[b], rec_cap, s->h_res[b]), "compress", c);
+            CK(mrcz_compress_chunks_int8_async(c, D->d_a[b], bt.units, bt.first_chunk, D->d_b[b], rec_cap, D->h_res[b]), "compress", c);
         else if (!p->int_mode)
-            CK(mrcz_uncompress_chunks_async(c, s->d_a[b], bt.in_bytes, bt.units, p->chk, s->d_b[b], s->h_res[b]), "uncompress", c);
+            CK(mrcz_uncompress_chunks_async(c, D->d_a[b], bt.in_bytes, bt.units, p->chk, D->d_b[b], D->h_res[b]), "uncompress", c);
         else
-            CK(mrcz_uncompress_chunks_int8_async(c, s->d_a[b], bt.in_bytes, bt.units, p->chk, bt.first_chunk, s->d_b[b], s->h_res[b]), "uncompress", c);
-        CK(mrcz_event_record(c, MRCZ_STREAM_COMPUTE, s->comp_ev[b]), "event record", c);
-        pthread_mutex_unlock(&s->e->mu);
+            CK(mrcz_uncompress_chunks_int8_async(c, D->d_a[b], bt.in_bytes, bt.units, p->chk, bt.first_chunk, D->d_b[b], D->h_res[b]), "uncompress", c);
+        CK(mrcz_event_record(c, MRCZ_STREAM_COMPUTE, D->comp_ev[b]), "event record", c);
+        pthread_mutex_unlock(&D->e->mu);
         pthread_mutex_lock(&p->mu);
-        p->q_done[b] = bt;
+        p->q_done[qi] = bt;
         p->n_enq = k + 1;
         pthread_cond_broadcast(&p->cv);
         pthread_mutex_unlock(&p->mu);
@@ -569,8 +628,10 @@ int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const 
     int batch = batch_chunks();
     const uint64_t file_chunks = (file_floats + CHUNK_SIZE - 1) / CHUNK_SIZE;
     if ((uint64_t)batch > file_chunks) batch = (int)file_chunks; /* a small file does not allocate a whole batch */
-    session_t *ses = session_get((uint64_t)batch * CHUNK_BYTES, mrcz_records_bound((uint64_t)batch * CHUNK_SIZE) + 64);
-    if (batch > ses->e->batch) batch = ses->e->batch;
+    int nd = thread_ndev(); /* one device per batch of the file at most */
+    if ((uint64_t)nd > (file_chunks + (uint64_t)batch - 1) / (uint64_t)batch) nd = (int)((file_chunks + (uint64_t)batch - 1) / (uint64_t)batch);
+    session_t *ses = session_get((uint64_t)batch * CHUNK_BYTES, mrcz_records_bound((uint64_t)batch * CHUNK_SIZE) + 64, nd);
+    if (batch > ses->d[0].e->batch) batch = ses->d[0].e->batch;
 
     mrczip_header_t hd;
     init_mrczip_header(&hd, 0);
@@ -580,7 +641,7 @@ int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const 
 
     pipe_t p;
     memset(&p, 0, sizeof(p));
-    p.s = ses; p.c = ses->e->c; p.fin = fin; p.fout = fout; p.decode = 0; p.int_mode = int_mode; p.bits = bitsToMask; p.chk = CHUNK_SIZE; p.total_floats = file_floats; p.batch_chunks = batch;
+    p.s = ses; p.nd = nd; p.fin = fin; p.fout = fout; p.decode = 0; p.int_mode = int_mode; p.bits = bitsToMask; p.chk = CHUNK_SIZE; p.total_floats = file_floats; p.batch_chunks = batch;
     p.fd_out = output_fd(fout, &p.out_off);
     p.t_setup = now_sec() - begin;
     run_pipeline(&p);
@@ -615,12 +676,14 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
     int batch = batch_chunks();
     const uint64_t file_chunks = (nfloats + chk - 1) / chk;
     if ((uint64_t)batch > file_chunks) batch = (int)file_chunks;
-    session_t *ses = session_get(mrcz_records_bound((uint64_t)batch * CHUNK_SIZE) + 64, (uint64_t)batch * CHUNK_BYTES);
-    if (batch > ses->e->batch) batch = ses->e->batch;
+    int nd = thread_ndev();
+    if ((uint64_t)nd > (file_chunks + (uint64_t)batch - 1) / (uint64_t)batch) nd = (int)((file_chunks + (uint64_t)batch - 1) / (uint64_t)batch);
+    session_t *ses = session_get(mrcz_records_bound((uint64_t)batch * CHUNK_SIZE) + 64, (uint64_t)batch * CHUNK_BYTES, nd);
+    if (batch > ses->d[0].e->batch) batch = ses->d[0].e->batch;
 
     pipe_t p;
     memset(&p, 0, sizeof(p));
-    p.s = ses; p.c = ses->e->c; p.fin = fin; p.fout = fout; p.decode = 1; p.int_mode = int_mode; p.chk = chk; p.total_floats = nfloats; p.batch_chunks = batch;
+    p.s = ses; p.nd = nd; p.fin = fin; p.fout = fout; p.decode = 1; p.int_mode = int_mode; p.chk = chk; p.total_floats = nfloats; p.batch_chunks = batch;
     p.fd_out = output_fd(fout, &p.out_off);
     p.t_setup = now_sec() - begin;
     run_pipeline(&p);

@@ -147,6 +147,23 @@ int mrcz_uncompress_chunks_int8_async(mrcz_ctx_t *ctx, const void *d_records, ui
  * src/tool/erasebytes.c:109-134): words [256, nwords) of a file &= mask(bits).  In place. */
 int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, uint64_t first_word_index, int bits);
 
+/*
+ * erroranalysis on the device (the reference's QA tool src/tool/erroranalysis.c:188-219,347-495: absolute and relative error of
+ * every point of a decoded file against the original, the K worst points).  The device selects; the ordering rules of the
+ * reference (topK, erroranalysis.c:61-91) run on the host over the handful of points that can matter.
+ *   mrcz_err_hist     histogram of the error keys (bit pattern of fabsf(n2 - n1); NaN = 0xffffffff) of n points: pass 0 bins key
+ *                     bits 31..21, pass 1 bits 20..10 of the points whose bits 31..21 == prefix, pass 2 bits 9..0 of the points
+ *                     whose bits 31..10 == prefix.  Accumulates across calls (a file in batches) until `reset`; hist (host,
+ *                     2048 x u64, optional) receives the running histogram.  Three passes give the K-th largest key exactly.
+ *   mrcz_err_collect  appends every point with key >= threshold_bits to d_points (16-byte records {u64 index, u32 n1, u32 n2},
+ *                     device memory, cap_points records) starting at record count_in; returns the new count (it may exceed the
+ *                     capacity: only the first cap_points records are stored).
+ */
+int mrcz_err_hist(mrcz_ctx_t *ctx, const void *d_orig, const void *d_dec, uint64_t n, int pass, uint32_t prefix, int reset,
+                  uint64_t hist[2048]);
+int mrcz_err_collect(mrcz_ctx_t *ctx, const void *d_orig, const void *d_dec, uint64_t n, uint64_t base_index, uint32_t threshold_bits,
+                     void *d_points, uint64_t cap_points, uint64_t count_in, uint64_t *count_out);
+
 /* Synthetic benchmark volumes generated on the device: words [first_index, first_index + nwords) of the integer generator
  * of SURVEY.md Appendix D (the known-answer inputs of the reference's containers; tests/util.py kat_words).  Lets a 64 GiB
  * volume exist without a host copy.  Synchronous. */

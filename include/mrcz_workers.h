@@ -63,8 +63,11 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
 extern int isTestThroughput; /* src/core/workers.c:39: 1 = skip all output writes (-d 1) */
 
 /* Extra knobs of the GPU implementation (not in the reference): HIP device used by the calling
- * thread (default 0) and chunks per device batch (default 8 = 192 MiB of input). */
+ * thread (default 0; mrcz_workers_set_devices for several) and chunks per device batch (default 8 = 192 MiB of input). */
 void mrcz_workers_set_device(int device);
+/* deal the batches of ONE file over `ndevices` GPUs starting at `first` (batch k -> device first + k mod ndevices);
+ * every device codes its chunk ranges independently and the records are written in file order.  Thread-local, like set_device. */
+void mrcz_workers_set_devices(int first, int ndevices);
 void mrcz_workers_set_batch_chunks(int chunks);
 
 /* src/include/adapt.h:30-49 */

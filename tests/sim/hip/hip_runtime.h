@@ -139,7 +139,8 @@ static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "sim"; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+/* SIM_DEVICES=n: the emulator pretends to have n devices (they share the host's memory): multi-device host logic on the CPU */
+static inline hipError_t hipGetDeviceCount(int *n) { const char *e = getenv("SIM_DEVICES"); *n = (e && atoi(e) > 0) ? atoi(e) : 1; return hipSuccess; }
 struct hipDeviceProp_t { int multiProcessorCount; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 1; return hipSuccess; }
 double sim_now();

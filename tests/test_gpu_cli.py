@@ -221,3 +221,39 @@ def test_reference_front_ends_run_on_the_drop_in_library(tmp_path, oracle):
     r = _run([exx, "-i", str(lst), "-t", "zip", "-o", str(zdir), "-b", "12", "-n", "1"])
     assert r.returncode == 0, r.stderr
     assert (zdir / "in.mrc.zip").read_bytes() == oracle.compress(w.tobytes(), 12)
+
+
+def test_one_file_over_two_engines_on_this_gpu(tmp_path, oracle):
+    """SURVEY 8(e) in the C host, rehearsed on one GPU: MRCZ_DEVICES=2 deals the batches of one file to two logical devices,
+    MRCZ_DEVICE_ALIAS=1 folds both onto the GPU that is present (two engines: contexts, streams, events, buffers of their
+    own).  Same container bytes as with one device, and as the oracle."""
+    exe = os.path.join(BIN, "mrc_tar")
+    n = 5 * util.CHUNK + 999
+    w = util.gauss_words(n, seed=12)
+    src, z, back = tmp_path / "in.mrc", tmp_path / "o.zip", tmp_path / "b.mrc"
+    src.write_bytes(w.tobytes())
+    env = dict(os.environ, MRCZ_DEVICES="2", MRCZ_DEVICE_ALIAS="1", MRCZ_BATCH_CHUNKS="1", MRCZ_TRACE="1")
+    r = _run([exe, "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip"], env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("mrcz_create") == 2, r.stderr
+    assert z.read_bytes() == oracle.compress(w.tobytes(), 8, threads=8)
+    r = _run([exe, "-i", str(z), "-o", str(back), "-t", "unzip"], env=env)
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == util.erase_expected(w, 8).tobytes()
+
+
+@pytest.mark.skipif(util.ref_binary("erroranalysis_c") is None, reason="oracle/_ref not present on this box")
+def test_erroranalysis_tool_matches_the_reference_tool(tmp_path):
+    """bin/erroranalysis (selection of the worst points on the GPU: radix select + candidate hand-back) prints
+    the same lines as the reference's erroranalysis on a 3-chunk volume against its own decoded file (script/run_full_test.sh:106)."""
+    exe, ref, tar = os.path.join(BIN, "erroranalysis"), util.ref_binary("erroranalysis_c"), os.path.join(BIN, "mrc_tar")
+    n = 2 * util.CHUNK + 4567
+    w = util.gauss_words(n, seed=21)
+    a, z, b = tmp_path / "a.mrc", tmp_path / "a.zip", tmp_path / "b.mrc"
+    a.write_bytes(w.tobytes())
+    assert _run([tar, "-i", str(a), "-o", str(z), "-b", "13", "-t", "zip"]).returncode == 0
+    assert _run([tar, "-i", str(z), "-o", str(b), "-t", "unzip"]).returncode == 0
+    for k in ("2", "10"):
+        mine, theirs = _run([exe, "-a", str(a), "-b", str(b), "-k", k]), _run([ref, "-a", str(a), "-b", str(b), "-k", k])
+        assert mine.returncode == 0 and theirs.returncode == 0, (mine.stderr, theirs.stderr)
+        assert mine.stdout == theirs.stdout and len(mine.stdout.splitlines()) == int(k)

@@ -18,6 +18,10 @@ def simbin(tmp_path_factory):
     util.load_sim()  # builds tests/sim/libmrcz_sim.so
     d = tmp_path_factory.mktemp("hostsim")
     out = {}
+    exe = d / "erroranalysis"
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu99", "-Wall", "-o", str(exe), os.path.join(HOST, "erroranalysis.c"),
+                           "-L" + util.SIM_DIR, "-lmrcz_sim", "-lpthread", "-lm", "-lstdc++", "-Wl,-rpath," + util.SIM_DIR])
+    out["erroranalysis"] = str(exe)
     for main in ("mrc_tar", "mrc_tarx"):
         exe = d / main
         subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu99", "-Wall", "-o", str(exe), os.path.join(HOST, main + ".c"),
@@ -86,3 +90,53 @@ def test_mrc_tarx_threads_share_one_engine(simbin, oracle, tmp_path):
     tdir.mkdir()
     r = _run([simbin["mrc_tarx"], "-i", str(lst), "-t", "zip", "-o", str(tdir), "-n", "2", "-d", "1"])
     assert r.returncode == 0 and all(os.path.getsize(tdir / f"{s}.mrc.zip") == 0 for s in datas)
+
+
+def test_one_file_dealt_over_two_devices(simbin, oracle, tmp_path):
+    """SURVEY 8(e) in the C host: the batches of ONE file are dealt round-robin to the visible devices (here two emulated
+    ones, one chunk per batch), every device codes its chunk ranges on its own engine, the writer threads put the records back
+    in file order: same container bytes as the oracle, and the same decoded file through the two-device decoder."""
+    n = 2 * util.CHUNK + 30000                       # three chunks: device 0 gets chunks 0 and 2, device 1 chunk 1
+    w = np.zeros(n, np.uint32)                       # all-zero planes keep the emulator fast; the header words and a noisy tail differ
+    w[:256] = util.kat_words(256)
+    w[util.CHUNK - 5000: util.CHUNK + 5000] = util.gauss_words(10000, seed=8, header=False)
+    w[-20000:] = util.poisson_words(20000, seed=9)[-20000:]
+    src, z, back = tmp_path / "in.mrc", tmp_path / "o.zip", tmp_path / "b.mrc"
+    src.write_bytes(w.tobytes())
+    env = {"SIM_DEVICES": "2", "MRCZ_BATCH_CHUNKS": "1", "MRCZ_TRACE": "1"}
+    r = _run([simbin["mrc_tar"], "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip"], env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("mrcz_create") == 2, r.stderr          # two engines were brought up
+    ref = oracle.compress(w.tobytes(), 8, threads=3)
+    assert z.read_bytes() == ref
+    r = _run([simbin["mrc_tar"], "-i", str(z), "-o", str(back), "-t", "unzip"], env=env)
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == util.erase_expected(w, 8).tobytes()
+    # one device only (-G 1): the same bytes
+    r = _run([simbin["mrc_tar"], "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip", "-G", "1"], env=env)
+    assert r.returncode == 0 and r.stderr.count("mrcz_create") == 1 and z.read_bytes() == ref
+
+
+@pytest.mark.skipif(util.ref_binary("erroranalysis_c") is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("k,nanat", [(1, 777), (2, 777), (7, 777), (5, 2), (6, None), (3, 0)])
+def test_erroranalysis_matches_the_reference_tool(simbin, tmp_path, k, nanat):
+    """erroranalysis (src/tool/erroranalysis.c) with the selection on the device: same lines on stdout as
+    the reference's tool -- masked data (many equal errors: the relative-error and first-point tie rules decide), a few
+    planted outliers, a NaN, files of different lengths."""
+    ref = util.ref_binary("erroranalysis_c")
+    w = util.gauss_words(50000, seed=k)
+    dec = util.erase_expected(w, 14)
+    f = dec.view(np.float32)
+    f[1234] += 3.5
+    f[40000] -= 3.5
+    if nanat is not None:
+        f[nanat] = np.float32(np.nan)          # a NaN difference is a wall in the reference's bubble passes
+        f[nanat + 5000] = np.float32(np.nan)
+    a, b = tmp_path / "a.bin", tmp_path / "b.bin"
+    a.write_bytes(w.tobytes())
+    b.write_bytes(dec.tobytes()[: 4 * 49000])           # the decoded file is shorter: the tools stop there
+    mine = _run([simbin["erroranalysis"], "-a", str(a), "-b", str(b), "-k", str(k)])
+    theirs = _run([ref, "-a", str(a), "-b", str(b), "-k", str(k)])
+    assert mine.returncode == 0 and theirs.returncode == 0, (mine.stderr, theirs.stderr)
+    assert mine.stdout == theirs.stdout, (mine.stdout, theirs.stdout)
+    assert len(mine.stdout.splitlines()) == k
