@@ -38,6 +38,8 @@ def load():
     lib.mrcz_uncompress_chunks_int8.argtypes = [vp, vp, u64, u64, u32, u64, vp, ctypes.POINTER(u64)]
     lib.mrcz_generate_kat_words.restype = i32
     lib.mrcz_generate_kat_words.argtypes = [vp, vp, u64, u64]
+    lib.mrcz_set_ztypes.restype = i32
+    lib.mrcz_set_ztypes.argtypes = [vp, ctypes.c_char_p]
     lib.mrcz_erase_bits.restype = i32
     lib.mrcz_erase_bits.argtypes = [vp, vp, u64, u64, i32]
     lib.mrcz_set_timing.restype = i32
@@ -57,5 +59,5 @@ EXPORTS = [
     "mrcz_host_malloc", "mrcz_host_free", "mrcz_copy_h2d", "mrcz_copy_d2h",
     "mrcz_event_create", "mrcz_event_destroy", "mrcz_event_record", "mrcz_stream_wait_event", "mrcz_event_sync",
     "mrcz_copy_h2d_async", "mrcz_copy_d2h_async", "mrcz_compress_chunks_async", "mrcz_uncompress_chunks_async",
-    "mrcz_generate_kat_words", "mrcz_err_hist", "mrcz_err_collect", "mrcz_compress_chunks_int8", "mrcz_uncompress_chunks_int8", "mrcz_compress_chunks_int8_async", "mrcz_uncompress_chunks_int8_async",
+    "mrcz_set_ztypes", "mrcz_generate_kat_words", "mrcz_err_hist", "mrcz_err_collect", "mrcz_compress_chunks_int8", "mrcz_uncompress_chunks_int8", "mrcz_compress_chunks_int8_async", "mrcz_uncompress_chunks_int8_async",
 ]

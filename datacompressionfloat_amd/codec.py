@@ -158,8 +158,11 @@ class MrcZipCodec:
         """read_mrczip_header + run_uncompress (src/core/workers.c:568-688); mode as for zip_bytes (the container does not
         record it: the reference needs -s int again on decode)."""
         fsz, chk, typ, ztypes = unpack_file_header(container)
-        if any(z != 0 for z in ztypes):
-            raise MrczError("only ZLIB_DEF byte streams (ztype 0) are supported")
+        if any(z not in (0, 2, 4) for z in ztypes):
+            raise MrczError("byte stream compressor types must be ZLIB_DEF (0), LZ4_DEF (2) or LZ4HC_DEF (4)")
+        rc = _LIB.mrcz_set_ztypes(self._ctx, bytes(bytearray(z & 0xff for z in ztypes)))
+        if rc != 0:
+            raise self._err("mrcz_set_ztypes", rc)
         nfl = fsz // 4
         if chk == 0:
             raise MrczError("chunk size 0 in header (the reference divides by it, src/core/workers.c:589)")

@@ -77,6 +77,7 @@ struct mrcz_ctx {
     uint32_t blk_grid;     /* workgroups of the persistent block decoder */
     unsigned long long *dbgphase; /* 8 counters per stream when phase profiling is on */
     int phase_profile;
+    uint32_t lz4_planes;   /* bit j: byte stream j of the containers to decode holds LZ4 blocks (mrcz_set_ztypes) */
     unsigned long long *errhist; /* erroranalysis: 2048 histogram bins + the candidate counter; allocated on first use */
     uint8_t *planes;       /* byte planes of one batch (stream s at s * CHK), both directions; allocated on first use */
     /* timing */
@@ -516,7 +517,7 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
     for (uint64_t c0 = 0; c0 < nchunks; c0 += ctx->max_chunks) {
         const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
         const uint64_t bfl = (nfloats - c0 * chk) < (uint64_t)nb * chk ? (nfloats - c0 * chk) : (uint64_t)nb * chk;
-        LAUNCH("k_parse_records", k_parse_records, dim3(1), dim3(64), rec, len, bfl, chk, ctx->dstreams, ctx->result);
+        LAUNCH("k_parse_records", k_parse_records, dim3(1), dim3(64), rec, len, bfl, chk, ctx->dstreams, ctx->result, ctx->lz4_planes);
         const uint32_t ns = 4 * nb;
         HIPCHK(hipMemsetAsync(ctx->ncand, 0, ns * sizeof(uint32_t), ctx->stream), "memset ncand");
         HIPCHK(hipMemsetAsync(ctx->njobs, 0, (4 + RAW_SEGS) * sizeof(uint32_t), ctx->stream), "memset njobs");
@@ -539,6 +540,7 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
         LAUNCH("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
                  ctx->fallback, ctx->phase_profile == 1 ? ctx->dbgphase : (unsigned long long *)NULL);
         LAUNCH("k_inflate_seq", k_inflate, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
+        if (ctx->lz4_planes) LAUNCH("k_lz4_blocks", k_lz4_blocks, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result);
         LAUNCH("k_merge_segments", k_merge_segments, dim3(512, nb), dim3(256), rec, ctx->scratch + 16, ctx->planes, ctx->segs, ctx->nseg, ctx->segidx, bfl,
                chk, out + c0 * chk, len, (uint64_t)4 * ctx->row_chunks * CHK, int_mode ? 1u : 0u, (first_chunk + c0) * (uint64_t)chk);
     }
@@ -706,6 +708,18 @@ extern "C" int mrcz_erase_bits(mrcz_ctx_t *ctx, void *d_words, uint64_t nwords, 
     hipStream_t lstream = ctx->stream;
     LAUNCH("k_erase_bits", k_erase_bits, dim3(2048), dim3(256), (uint32_t *)d_words, nwords, first_word_index, mask_of(bits));
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (erase)");
+    return MRCZ_OK;
+}
+
+extern "C" int mrcz_set_ztypes(mrcz_ctx_t *ctx, const signed char ztypes[4])
+{
+    if (!ctx || !ztypes) return MRCZ_EINVAL;
+    uint32_t m = 0;
+    for (int j = 0; j < 4; j++) {
+        if (ztypes[j] == 2 || ztypes[j] == 4) m |= 1u << j;          /* LZ4_DEF / LZ4HC_DEF: both decode as LZ4 blocks (zip.c:306-318) */
+        else if (ztypes[j] != 0) return fail(ctx, MRCZ_EFORMAT, "byte stream compressor type is neither ZLIB_DEF (0), LZ4_DEF (2) nor LZ4HC_DEF (4)", hipSuccess);
+    }
+    ctx->lz4_planes = m;
     return MRCZ_OK;
 }
 

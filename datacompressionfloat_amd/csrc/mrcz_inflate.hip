@@ -20,13 +20,14 @@ namespace mrcz {
 struct DecStream {
     uint64_t payoff;
     uint32_t paylen;
-    uint32_t raw;
+    uint32_t raw;    /* 0 = raw-deflate payload, 1 = RAW plane (zip.c:184-190), 2 = LZ4 block (ztypes 2 / 4, zip.c:69-86) */
     uint32_t n;      /* plane bytes to produce */
     uint32_t pad;
 };
 
 __global__ void k_parse_records(const uint8_t *__restrict__ rec, uint64_t len, uint64_t nfloats, uint32_t chk,
-                                DecStream *__restrict__ ds, uint64_t *__restrict__ result /* [0] consumed, [1] error */)
+                                DecStream *__restrict__ ds, uint64_t *__restrict__ result /* [0] consumed, [1] error */,
+                                uint32_t lz4_planes /* bit j: byte stream j holds LZ4 blocks (header ztypes[j] = 2 or 4) */)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint64_t off = result[0]; /* where the previous batch of this call stopped (0 for the first) */
@@ -43,7 +44,7 @@ __global__ void k_parse_records(const uint8_t *__restrict__ rec, uint64_t len, u
             const uint8_t *h = rec + off + 4 * j;
             const uint32_t raw = (h[3] & 0x80u) >> 7;
             const uint32_t l = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)(h[3] & 0x7fu) << 24);
-            d4[j].payoff = p; d4[j].paylen = l; d4[j].raw = raw; d4[j].n = n; d4[j].pad = 0;
+            d4[j].payoff = p; d4[j].paylen = l; d4[j].raw = raw ? 1u : (((lz4_planes >> j) & 1u) ? 2u : 0u); d4[j].n = n; d4[j].pad = 0;
             /* a deflate stream of n bytes is never longer than n + n/8 + a few bytes (stored blocks: 5 per 65535); anything
              * larger is not a plane of this container (and 8 * paylen must stay below 2^32 for the bit positions) */
             if (p + l > len || (raw && l < n) || (!raw && l > CHK + (CHK >> 3) + 1024u)) err = 1;
@@ -251,6 +252,59 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ rec,
         if (final) break;
     }
     if (bad || op != d.n) atomicAdd((unsigned long long *)&result[1], 1ull);
+}
+
+/* Decoder tolerance for LZ4 / LZ4HC byte streams (header ztypes 2 / 4; mlz4_inf -> LZ4_uncompress(in, out, outlen) of the
+ * vendored src/core/lz4.c, /root/reference/src/core/zip.c:69-86).  The reference's writer never selects them
+ * (workers.c:719), so this is not a fast path: one wave per stream walks the block's sequences one after the other
+ * (token, literal-length bytes, literals, 2-byte offset, match-length bytes; published LZ4 block format); the wave copies
+ * the literals and the match together -- a match that overlaps its own output repeats the `offset` bytes before it, so
+ * byte i of the match is out[op - offset + i mod offset] and all its bytes can be written at once. */
+__global__ __launch_bounds__(64) void k_lz4_blocks(const uint8_t *__restrict__ rec, const DecStream *__restrict__ ds,
+                                                   uint8_t *__restrict__ planes, uint64_t *__restrict__ result)
+{
+    const uint32_t s = blockIdx.x;
+    const DecStream d = ds[s];
+    if (d.raw != 2u) return;
+    const uint8_t *in = rec + d.payoff;
+    uint8_t *out = planes + (size_t)s * CHK;
+    const uint32_t inlen = d.paylen, outlen = d.n;
+    const uint32_t lane = threadIdx.x;
+    uint32_t ip = 0, op = 0;
+    bool bad = false;
+    while (op < outlen) { /* every lane follows the same sequence headers (uniform loads) */
+        if (ip >= inlen) { bad = true; break; }
+        const uint32_t token = in[ip++];
+        uint32_t ll = token >> 4;
+        if (ll == 15u) {
+            uint32_t b;
+            do { if (ip >= inlen) { bad = true; break; } b = in[ip++]; ll += b; } while (b == 255u);
+            if (bad) break;
+        }
+        if (ll > inlen - ip || ll > outlen - op) { bad = true; break; }
+        for (uint32_t i = lane; i < ll; i += 64u) out[op + i] = in[ip + i];
+        ip += ll; op += ll;
+        if (op == outlen) break; /* the last sequence has no match */
+        if (ip + 2u > inlen) { bad = true; break; }
+        const uint32_t off = (uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8);
+        ip += 2u;
+        if (off == 0u || off > op) { bad = true; break; }
+        uint32_t ml = token & 15u;
+        if (ml == 15u) {
+            uint32_t b;
+            do { if (ip >= inlen) { bad = true; break; } b = in[ip++]; ml += b; } while (b == 255u);
+            if (bad) break;
+        }
+        ml += 4u;
+        if (ml > outlen - op) { bad = true; break; }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block(); /* the literals just written may be the match's source */
+        for (uint32_t i = lane; i < ml; i += 64u) out[op + i] = out[op - off + (i % off)];
+        op += ml;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+    if (bad && lane == 0) atomicAdd((unsigned long long *)&result[1], 1ull);
 }
 
 /* apply_mask alone (erasebytes restatement, src/tool/erasebytes.c:109-134) */

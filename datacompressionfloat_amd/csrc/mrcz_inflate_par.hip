@@ -1459,7 +1459,8 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
         }
         for (uint32_t t = (uint32_t)lane; t < ntile; t += 64u) ix[t] = 0;
     };
-    if (d.raw) { single(SEG_REC | d.payoff); if (lane == 0) fallback[s] = 0; return; }
+    if (d.raw == 1u) { single(SEG_REC | d.payoff); if (lane == 0) fallback[s] = 0; return; }
+    if (d.raw == 2u) { single(SEG_PLANES | ((uint64_t)s * CHK)); if (lane == 0) fallback[s] = 0; return; } /* LZ4 block: k_lz4_blocks decodes it into the plane buffer */
     if (force_fallback || d.n == 0) { single(SEG_PLANES | ((uint64_t)s * CHK)); if (lane == 0) fallback[s] = d.n ? 1u : 0u; return; }
     uint32_t nc = ncand[s];
     bool fail = nc > (uint32_t)MAXCAND;

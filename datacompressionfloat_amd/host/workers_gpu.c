@@ -240,6 +240,7 @@ typedef struct {
     FILE *fin, *fout;
     int decode;           /* 0 = run_compress, 1 = run_uncompress */
     int int_mode;         /* dataConvertedType == "int" (workers.c:782-787, 604-609) */
+    signed char ztypes[4];/* decode: compressor types of the four byte streams (file header) */
     int bits;
     uint32_t chk;         /* floats per chunk */
     uint64_t total_floats;/* decode: floats of the file */
@@ -593,6 +594,7 @@ static void run_pipeline(pipe_t *p)
             CK(mrcz_compress_chunks_async(c, D->d_a[b], bt.units, bt.first_chunk, p->bits, D->d_b[b], rec_cap, D->h_res[b]), "compress", c);
         else if (!p->decode)
             CK(mrcz_compress_chunks_int8_async(c, D->d_a[b], bt.units, bt.first_chunk, D->d_b[b], rec_cap, D->h_res[b]), "compress", c);
+        else if (mrcz_set_ztypes(c, p->ztypes) != MRCZ_OK) die("ztypes", c); /* (under the engine's mutex: other threads' files may differ) */
         else if (!p->int_mode)
             CK(mrcz_uncompress_chunks_async(c, D->d_a[b], bt.in_bytes, bt.units, p->chk, D->d_b[b], D->h_res[b]), "uncompress", c);
         else
@@ -660,9 +662,8 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
 {
     const int int_mode = dataConvertedType && strcmp(dataConvertedType, "int") == 0; /* workers.c:604, 646 */
     for (int j = 0; j < COMPRESSION_PATH_NUM; j++)
-        if (hd->ztypes[j] != 0) { /* LZ4 / LZ4HC streams are never written by the reference (workers.c:719) */
-            fprintf(stderr, "[%s:%d] ERROR: byte stream %d uses compressor type %d; only ZLIB_DEF (0) is supported\n", __FILE__, __LINE__,
-                    j, hd->ztypes[j]);
+        if (hd->ztypes[j] != 0 && hd->ztypes[j] != 2 && hd->ztypes[j] != 4) { /* ZLIB_DEF, LZ4_DEF, LZ4HC_DEF (mrczip.h:37-40); init_mrc_zip_stream rejects the rest (zip.c:319-321) */
+            fprintf(stderr, "[%s:%d] ERROR: byte stream %d uses unknown compressor type %d\n", __FILE__, __LINE__, j, hd->ztypes[j]);
             exit(-1);
         }
     if (hd->chk == 0 || hd->chk > CHUNK_SIZE) { /* the reference divides by chk (workers.c:589) */
@@ -685,6 +686,7 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
     memset(&p, 0, sizeof(p));
     p.s = ses; p.nd = nd; p.fin = fin; p.fout = fout; p.decode = 1; p.int_mode = int_mode; p.chk = chk; p.total_floats = nfloats; p.batch_chunks = batch;
     p.fd_out = output_fd(fout, &p.out_off);
+    memcpy(p.ztypes, hd->ztypes, 4);
     p.t_setup = now_sec() - begin;
     run_pipeline(&p);
     if (p.fd_out >= 0) fseeko(fout, (off_t)p.out_off, SEEK_SET);

@@ -86,6 +86,12 @@ int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats, ui
 int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, uint64_t len, uint64_t nfloats,
                            uint32_t chk, void *d_out, uint64_t *consumed);
 
+/* Compressor types of the four byte streams of the containers the context will decode, as the 17-byte file header records
+ * them (ztypes[4], src/core/common.c:143-146; enum src/include/mrczip.h:37-40): 0 = ZLIB_DEF (what every writer of the
+ * reference produces, workers.c:719), 2 = LZ4_DEF, 4 = LZ4HC_DEF (decoder tolerance: the reference's reader accepts them,
+ * workers.c:584, zip.c:69-86,306-318).  Default all 0; stays in force until set again.  Anything else: MRCZ_EFORMAT. */
+int mrcz_set_ztypes(mrcz_ctx_t *ctx, const signed char ztypes[4]);
+
 /* Plain-C device memory helpers so that C host code (the C files under datacompressionfloat_amd/host) needs no HIP
  * headers: device buffers, pinned host buffers, synchronous copies on the context's stream. */
 int mrcz_device_count(void);

@@ -767,6 +767,44 @@ done:
 }
 
 /* ------------------------------------------------------------------------------------------
+ * LZ4 block decode (decoder tolerance for ztypes LZ4_DEF = 2 / LZ4HC_DEF = 4: src/core/zip.c:69-86 mlz4_inf calls
+ * LZ4_uncompress(in, out, outlen) of the vendored src/core/lz4.c; a writer of the reference never selects them,
+ * workers.c:719).  Restated from the published LZ4 block format: sequences of
+ *   token (hi nibble = literal length, lo nibble = match length - 4; 15 = more length bytes follow, each adding up to 255),
+ *   literals, 2-byte little-endian offset, optional match-length bytes; the last sequence ends after its literals.
+ * Decodes exactly outlen bytes (the old LZ4_uncompress contract); returns input bytes consumed or -1.
+ * ---------------------------------------------------------------------------------------- */
+int64_t mrcz_oracle_lz4_decode(const uint8_t *in, uint64_t inlen, uint8_t *out, uint64_t outlen)
+{
+    uint64_t ip = 0, op = 0;
+    for (;;) {
+        if (ip >= inlen) return -1;
+        const unsigned token = in[ip++];
+        uint64_t ll = token >> 4;
+        if (ll == 15) {
+            unsigned b;
+            do { if (ip >= inlen) return -1; b = in[ip++]; ll += b; } while (b == 255);
+        }
+        if (ip + ll > inlen || op + ll > outlen) return -1;
+        memcpy(out + op, in + ip, (size_t)ll);
+        ip += ll; op += ll;
+        if (op == outlen) return (int64_t)ip; /* the last sequence has no match */
+        if (ip + 2 > inlen) return -1;
+        const uint64_t off = (uint64_t)in[ip] | ((uint64_t)in[ip + 1] << 8);
+        ip += 2;
+        if (off == 0 || off > op) return -1;
+        uint64_t ml = token & 15u;
+        if (ml == 15) {
+            unsigned b;
+            do { if (ip >= inlen) return -1; b = in[ip++]; ml += b; } while (b == 255);
+        }
+        ml += 4;
+        if (op + ml > outlen) return -1;
+        for (uint64_t i = 0; i < ml; i++, op++) out[op] = out[op - off]; /* may overlap */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * container
  * ---------------------------------------------------------------------------------------- */
 uint64_t mrcz_oracle_bound(uint64_t fsz)
@@ -854,8 +892,12 @@ int64_t mrcz_oracle_uncompress(const uint8_t *zin, uint64_t zlen, uint8_t *out, 
     memcpy(&fsz, zin, 8);
     memcpy(&chk, zin + 8, 4);
     if (chk == 0 || chk >= 0x80000000u) return -1;
-    for (int j = 0; j < 4; j++)
-        if (zin[13 + j] != 0) return -1; /* only ZLIB_DEF streams (ztype 0) are in scope */
+    int lz4[4];
+    for (int j = 0; j < 4; j++) { /* common.h / mrczip.h:37-40: 0 = ZLIB_DEF, 2 = LZ4_DEF, 4 = LZ4HC_DEF (decoder = ztype + 1, workers.c:584) */
+        const int zt = (signed char)zin[13 + j];
+        if (zt != 0 && zt != 2 && zt != 4) return -1;
+        lz4[j] = zt != 0;
+    }
     uint64_t nfl = fsz / 4;
     if (cap < nfl * 4) return -1;
     uint64_t ip = MRCZ_FILE_HDR;
@@ -876,6 +918,9 @@ int64_t mrcz_oracle_uncompress(const uint8_t *zin, uint64_t zlen, uint8_t *out, 
             if (raw) {
                 if (len < num) goto done;
                 src[j] = (uint8_t *)(zin + ip);
+            } else if (lz4[j]) { /* zip.c:69-86 mlz4_inf */
+                if (mrcz_oracle_lz4_decode(zin + ip, len, planes[j], num) < 0) goto done;
+                src[j] = planes[j];
             } else {
                 if (mrcz_oracle_inflate(zin + ip, len, planes[j], num) != (int64_t)num) goto done;
                 src[j] = planes[j];

@@ -57,6 +57,9 @@ int64_t mrcz_oracle_deflate_zlib(const uint8_t *plane, uint32_t n, uint8_t *out,
  * produced or input ends).  General DEFLATE (any distance).  Returns bytes produced or -1. */
 int64_t mrcz_oracle_inflate(const uint8_t *in, uint64_t inlen, uint8_t *out, uint64_t outlen);
 
+/* LZ4 block decode to exactly outlen bytes (src/core/zip.c:69-86 mlz4_inf -> LZ4_uncompress); bytes consumed or -1 */
+int64_t mrcz_oracle_lz4_decode(const uint8_t *in, uint64_t inlen, uint8_t *out, uint64_t outlen);
+
 /* Upper bound of the container size for an input of fsz bytes. */
 uint64_t mrcz_oracle_bound(uint64_t fsz);
 

@@ -61,6 +61,47 @@ def ref_unzip(z: bytes, mode: str = "float") -> bytes:
         return open(o, "rb").read()
 
 
+def lz4_container(data: bytes, hc: bool) -> bytes:
+    """A container whose four byte streams are LZ4 (ztype 2) or LZ4HC (ztype 4) blocks, built the way run_compress would
+    build it with LZ4_DEF / LZ4HC_DEF selected (zip.c:32-67 _lz4_def: COMPRESSED iff the compressor returned > 0, i.e. the
+    block fits in inlen bytes) -- the reference's writer never selects them (workers.c:719), its reader accepts them
+    (workers.c:584, zip.c:306-318).  The blocks come from the reference's own vendored LZ4 (src/core/lz4.c, lz4hc.c), compiled
+    into oracle/_ref/libmrcref.so."""
+    import ctypes, struct
+    lib = ctypes.CDLL(os.path.join(util.REF_DIR, "libmrcref.so"))
+    fn = lib.LZ4_compressHC_limitedOutput if hc else lib.LZ4_compress_limitedOutput
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    n = len(data) // 4
+    w = np.frombuffer(data[: 4 * n], np.uint32)
+    b = w.view(np.uint8).reshape(-1, 4)
+    zt = 4 if hc else 2
+    out = bytearray(struct.pack("<QIb4b", len(data), util.CHUNK, 0, zt, zt, zt, zt))
+    for c0 in range(0, n, util.CHUNK):
+        c1 = min(n, c0 + util.CHUNK)
+        hdr, pay = bytearray(), bytearray()
+        for j in range(4):
+            plane = np.ascontiguousarray(b[c0:c1, j]).tobytes()
+            buf = ctypes.create_string_buffer(len(plane) + 64)
+            zl = fn(plane, buf, len(plane), len(plane))
+            if zl > 0:
+                hdr += struct.pack("<I", zl)
+                pay += buf.raw[:zl]
+            else:
+                hdr += struct.pack("<I", len(plane) | 0x80000000)
+                pay += plane
+        out += hdr + pay
+    return bytes(out)
+
+
+def lz4_cases():
+    """name -> (input bytes, hc): runs (long matches, overlapping copies), detector counts (short literals and matches), noise (RAW)"""
+    return {"lz4_runs": (util.runs_words(30000, [1, 2, 3, 5, 17, 300, 1000, 5000], 3, seed=31).tobytes(), False),
+            "lz4_poisson": (util.poisson_words(50000, seed=32).tobytes(), False),
+            "lz4hc_poisson": (util.poisson_words(50000, seed=33).tobytes(), True),
+            "lz4_gauss_tail1": (util.gauss_words(20001, seed=34).tobytes() + b"\x09", False)}
+
+
 def int_cases():
     """name -> input bytes for the "-s int" mode (workers.c:125-175,444-511): committed with the reference's containers"""
     return {"int5000": util.int_mode_words(5000, seed=21).tobytes(),
@@ -109,6 +150,13 @@ def main():
         assert dec == exp, name                          # the numpy statement of the quantiser agrees with the reference binary
         golden["int_mode"][name] = {"input_bytes": len(data), "input_sha256": util.sha256(data), "size": len(z), "sha256": util.sha256(z),
                                     "decoded_sha256": util.sha256(dec)}
+    # decoder tolerance: LZ4 / LZ4HC byte streams (ztypes 2 / 4); the reference binary must decode them to the input
+    golden["lz4"] = {}
+    for name, (data, hc) in lz4_cases().items():
+        z = lz4_container(data, hc)
+        assert ref_unzip(z) == data[: len(data) // 4 * 4], name
+        open(os.path.join(HERE, name + ".zip"), "wb").write(z)
+        golden["lz4"][name] = {"input_bytes": len(data), "input_sha256": util.sha256(data), "size": len(z), "sha256": util.sha256(z), "hc": hc}
     # larger seeded shapes (scaled to a few chunks): hashes only
     big = {
         "gauss_4Mi_b8": (util.gauss_words(4 * 1048576, seed=1234).tobytes(), 8),         # one partial chunk

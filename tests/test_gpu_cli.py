@@ -257,3 +257,14 @@ def test_erroranalysis_tool_matches_the_reference_tool(tmp_path):
         mine, theirs = _run([exe, "-a", str(a), "-b", str(b), "-k", k]), _run([ref, "-a", str(a), "-b", str(b), "-k", k])
         assert mine.returncode == 0 and theirs.returncode == 0, (mine.stderr, theirs.stderr)
         assert mine.stdout == theirs.stdout and len(mine.stdout.splitlines()) == int(k)
+
+
+def test_mrc_tar_decodes_lz4_containers(tmp_path):
+    """the C host passes the header's ztypes on (run_uncompress, workers.c:584): an LZ4HC container through bin/mrc_tar"""
+    from golden.make_golden import lz4_cases
+    exe = os.path.join(BIN, "mrc_tar")
+    data, hc = lz4_cases()["lz4hc_poisson"]
+    out = tmp_path / "o.mrc"
+    r = _run([exe, "-i", os.path.join(util.GOLDEN, "lz4hc_poisson.zip"), "-o", str(out), "-t", "unzip"])
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == data

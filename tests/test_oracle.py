@@ -141,3 +141,15 @@ def test_int_mode_oracle_matches_live_reference_binary(oracle):
         assert oracle.compress_int(w.tobytes()) == z
         subprocess.check_call([ref, "-i", dst, "-o", back, "-t", "unzip", "-s", "int"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         assert open(back, "rb").read() == oracle.uncompress(z, int_mode=True) == util.int_mode_expected(w).tobytes()
+
+
+def test_oracle_decodes_lz4_byte_streams(oracle):
+    """ztypes 2 / 4 (LZ4_DEF / LZ4HC_DEF, mrczip.h:37-40): fixtures built with the reference's vendored LZ4 and decoded by the
+    reference binary when they were generated (make_golden.py); the oracle's own LZ4 block decoder must give the input back."""
+    from golden.make_golden import lz4_cases
+    for name, (data, hc) in lz4_cases().items():
+        meta = G["lz4"][name]
+        z = open(os.path.join(util.GOLDEN, name + ".zip"), "rb").read()
+        assert util.sha256(z) == meta["sha256"] and util.sha256(data) == meta["input_sha256"]
+        assert z[13:17] == bytes([4 if hc else 2] * 4)
+        assert oracle.uncompress(z) == data[: len(data) // 4 * 4], name

@@ -79,3 +79,18 @@ def test_device_generator_equals_the_appendix_d_generator(simlib):
     # the LCG has period 2^32 (two steps per word) and the stripe pattern period 2^14: word i + 2^31 == word i
     assert np.array_equal(simlib.generate_kat((1 << 31) + 5, 9000), ref[5:9005])
     assert np.array_equal(simlib.generate_kat((1 << 34) + (1 << 31) + 4090, 100), ref[4090:4190])
+
+
+def test_lz4_byte_streams_decode(simlib, oracle):
+    """Decoder tolerance: containers whose byte streams are LZ4 / LZ4HC blocks (header ztypes 2 / 4), written
+    with the reference's own vendored LZ4 by tests/golden/make_golden.py and verified there with the reference binary."""
+    from golden.make_golden import lz4_cases
+    for name, (data, hc) in lz4_cases().items():
+        z = open(os.path.join(util.GOLDEN, name + ".zip"), "rb").read()
+        n = len(data) // 4
+        assert oracle.uncompress(z) == data[: 4 * n], name
+        assert simlib.set_ztypes(list(z[13:17])) == 0
+        got = simlib.uncompress_records(z[17:], n)
+        assert got.tobytes() == data[: 4 * n], name
+    assert simlib.set_ztypes([0, 1, 0, 0]) != 0      # ZLIB_INF is not a stream type a file can carry
+    assert simlib.set_ztypes([0, 0, 0, 0]) == 0

@@ -223,6 +223,7 @@ class SimCodec:
         lib.mrcz_compress_chunks_int8.argtypes = [vp, vp, u64, u64, vp, u64, ctypes.POINTER(u64), vp]
         lib.mrcz_uncompress_chunks_int8.argtypes = [vp, vp, u64, u64, u32, u64, vp, ctypes.POINTER(u64)]
         lib.mrcz_generate_kat_words.argtypes = [vp, vp, u64, u64]
+        lib.mrcz_set_ztypes.argtypes = [vp, ctypes.c_char_p]
         lib.mrcz_last_error.restype = ctypes.c_char_p
         lib.mrcz_last_error.argtypes = [vp]
         lib.mrcz_debug_fallbacks.restype = ctypes.c_int64
@@ -244,6 +245,9 @@ class SimCodec:
         if rc != 0:
             raise RuntimeError(f"sim compress rc={rc}: {self.lib.mrcz_last_error(self.ctx)}")
         return dout[:olen.value].tobytes()
+
+    def set_ztypes(self, ztypes) -> int:
+        return self.lib.mrcz_set_ztypes(self.ctx, bytes(bytearray(z & 0xff for z in ztypes)))
 
     def generate_kat(self, first: int, n: int) -> np.ndarray:
         out = aligned_empty(4 * n).view(np.uint32)
