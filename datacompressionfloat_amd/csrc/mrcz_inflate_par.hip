@@ -39,7 +39,12 @@ constexpr int PT = 512;                       /* threads per workgroup (3 workgr
 constexpr int SUBBITS = 256;                  /* bits per lane piece */
 constexpr int WINBITS = PT * SUBBITS;         /* 16 KiB of compressed data per window */
 constexpr int MAXTOK = 24;                    /* longest token (bits) the parallel path resolves */
-constexpr uint32_t X_ERR = 30u, X_EOB = 31u;
+/* exit value "the token chain stops in this piece": END_BLOCK, or a token the parallel path cannot follow (invalid code, distance
+ * code beyond the fast table, longer than MAXTOK bits).  ONE value for both: the lane whose walk reaches that token tells them
+ * apart (count_walk), the pieces behind it are simply inactive.  28 so that position k + 28 falls into the ring row that is dead
+ * while the group of k is processed (piece_exit_word). */
+constexpr uint32_t X_STOP = 28u;
+constexpr uint32_t X_ERR = X_STOP, X_EOB = X_STOP;
 constexpr int WIN_WORDS = WINBITS / 32 + 8;   /* + alignment lead + lookahead */
 constexpr int HDR_WORDS = 192;                /* staged bits for a dynamic header */
 constexpr int LBITS = 12;                     /* index bits of the literal/length fast tables */
@@ -99,6 +104,7 @@ struct ParShared {
     uint32_t lead;      /* scratch mode: bytes the block produces before its first literal */
     uint32_t nwin;      /* windows of the current block so far */
     unsigned long long acc[20], tp; /* phase counters (profiling builds of the call only) */
+    uint32_t complete;  /* every entry of the token table carries its token's bits (no entry says "ask token_bits()") */
     uint32_t dmax;      /* longest distance code + extra bits of the current block */
     uint32_t mintok;    /* shortest literal/length code of the current block (every token is at least that long) */
     uint32_t maxtok;    /* longest token of the current block, bits (<= MAXTOK on the parallel path) */
@@ -289,7 +295,7 @@ __device__ __forceinline__ uint32_t ring_off(uint32_t x)
     static_assert(PT * 4 == 2048, "ring_off assumes 2 KiB rows");
     return (x * 0x201u) & 0x3803u;
 }
-template <bool TAIL, bool MIN4>
+template <bool TAIL, bool MIN4, bool COMPLETE>
 __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int wq, uint32_t lead)
 {
     /* the window is staged dword-aligned, its first token starts `lead` (< 32) bits in: funnel the piece's dwords
@@ -304,6 +310,11 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
     const uint32_t lane4 = tid << 2; /* my column: bits 2..10 of a ring byte offset (row = bits 11..13, byte = bits 0..1) */
 #pragma unroll
     for (int q = 7; q >= 0; q--) {
+        /* A token is at most MAXTOK = 24 bits, so while the group of positions k .. k+3 is processed the ring row of positions
+         * k+28 .. k+31 is dead.  Filled with X_STOP it makes the exit of an END_BLOCK / unresolvable token (token bits = X_STOP
+         * = 28 in the table) come out of the same ring read as every other exit: no test, no branch.  (The last word of the
+         * piece, TAIL, has no row beyond it and keeps the explicit form.) */
+        if (!TAIL) sh.ring[(q + 7) & 7][tid] = X_STOP * 0x01010101u;
         uint32_t tt[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -312,26 +323,25 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
                                           : (uint32_t)(w01x4 >> sft) & (((1u << LBITS) - 1u) << 2);
             tt[j] = tokb[off]; /* byte 0 of the entry: token bits */
         }
-        if ((tt[0] == 0u) | (tt[1] == 0u) | (tt[2] == 0u) | (tt[3] == 0u)) {
+        if (!COMPLETE) { /* some table entries say "ask token_bits()" (codes longer than the index, matches that do not fit in it) */
+            if ((tt[0] == 0u) | (tt[1] == 0u) | (tt[2] == 0u) | (tt[3] == 0u)) {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (tt[j] == 0u) tt[j] = token_bits(sh, w01 >> (4 * q + j));
+                for (int j = 0; j < 4; j++)
+                    if (tt[j] == 0u) tt[j] = token_bits(sh, w01 >> (4 * q + j));
+            }
         }
         uint32_t ex[4], x[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             x[j] = kbase + (uint32_t)(4 * q + j) + tt[j];
-            ex[j] = ringb[ring_off(x[j]) | lane4];
-        }
-        /* END_BLOCK / unresolvable tokens are rare: one test for the group instead of a select per position */
-        const uint32_t tmax = max(max(tt[0], tt[1]), max(tt[2], tt[3]));
-        if (tmax >= X_ERR) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) ex[j] = tt[j] >= X_ERR ? tt[j] : ex[j];
+            /* ring_off(x) with the position's part folded into a wave-uniform constant */
+            const uint32_t c = (kbase + (uint32_t)(4 * q + j)) * 0x201u;
+            ex[j] = ringb[((tt[j] * 0x201u + c) & 0x3803u) | lane4];
         }
         if (TAIL) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) ex[j] = (tt[j] < X_ERR && x[j] >= (uint32_t)SUBBITS) ? x[j] - (uint32_t)SUBBITS : ex[j];
+            for (int j = 0; j < 4; j++)
+                ex[j] = tt[j] >= X_STOP ? X_STOP : (x[j] >= (uint32_t)SUBBITS ? x[j] - (uint32_t)SUBBITS : ex[j]);
         }
         if (!MIN4) {
             /* tokens shorter than 4 bits land inside this group of four, on a position whose exit is not in LDS yet:
@@ -346,11 +356,11 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
         sh.ring[q][tid] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (ex[3] << 24); /* positions kbase + 4q .. + 3 */
     }
 }
-template <bool MIN4>
+template <bool MIN4, bool COMPLETE>
 __device__ __forceinline__ void piece_exit_lds(ParShared &sh, uint32_t tid, uint32_t lead)
 {
-    piece_exit_word<true, MIN4>(sh, tid, SUBBITS / 32 - 1, lead);
-    for (int wq = SUBBITS / 32 - 2; wq >= 0; wq--) piece_exit_word<false, MIN4>(sh, tid, wq, lead);
+    piece_exit_word<true, MIN4, COMPLETE>(sh, tid, SUBBITS / 32 - 1, lead);
+    for (int wq = SUBBITS / 32 - 2; wq >= 0; wq--) piece_exit_word<false, MIN4, COMPLETE>(sh, tid, wq, lead);
 }
 
 
@@ -416,11 +426,15 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
             const uint32_t ml = base_len_of(lc) + ((uint32_t)buf & ((1u << xb) - 1u));
             buf >>= xb; nb -= xb; pos += (uint32_t)xb;
             if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
+            /* what the exit functions (token_bits) call unresolvable must be flagged by the lane that walks into it: the pieces
+             * behind it only know that the chain stopped */
+            if (!sh.dist.lut[(uint32_t)buf & ((1u << DBITS) - 1u)]) { r.flags |= F_ERR; break; } /* distance code beyond the fast table */
             const uint32_t dd = huff_decode_dist(sh.dist, (uint32_t)buf);
             if (dd == 0xffffffffu || (dd & 0xffffu) >= 30u) { r.flags |= F_ERR; break; }
             const int dl = (int)(dd >> 16), dc = (int)(dd & 0xffffu);
             buf >>= dl; nb -= dl; pos += (uint32_t)dl;
             const int dxb = dc < 4 ? 0 : (dc >> 1) - 1;
+            if (l + xb + dl + dxb > MAXTOK) { r.flags |= F_ERR; break; }                          /* longer than the exit functions follow */
             const uint32_t dist = base_dist_of(dc) + ((uint32_t)buf & ((1u << dxb) - 1u));
             buf >>= dxb; nb -= dxb; pos += (uint32_t)dxb;
             if (dist != 1u) r.flags |= F_GENERAL;
@@ -431,67 +445,41 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
     return r;
 }
 
-/* Per-lane output packer of the write walk.  A lane's plane bytes are contiguous in HBM but start at any byte
- * address and come one token at a time; storing them byte by byte costs one scattered store instruction per
- * byte.  The packer collects them in a 64-bit register and stores four at a time with ONE (generally unaligned)
- * dword store -- gfx9 global memory takes unaligned dword accesses.  All lanes start empty, so in a literal run
- * every lane of the wave flushes in the same iteration and the store instruction runs with a full exec mask. */
-struct OutPacker {
-    uint8_t *p;              /* where the low byte of acc goes */
-    unsigned long long acc;  /* pending bytes */
-    uint32_t fill;           /* bytes held in acc (< 4 between calls) */
-};
-__device__ __forceinline__ void pk_init(OutPacker &k, uint8_t *out)
-{
-    k.p = out;
-    k.acc = 0;
-    k.fill = 0;
-}
+/* one (generally unaligned) dword store: gfx9 global memory takes unaligned dword accesses */
 __device__ __forceinline__ void pk_store4(uint8_t *p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
-__device__ __forceinline__ void pk_flush_word(OutPacker &k)
+
+/* A token the table does not resolve in one look-up (code longer than the index, match whose fields do not fit, END_BLOCK),
+ * decoded straight from the staged window at bit `pos`: bits | bytes produced << 8 | (literal: 1 << 17 | byte << 18);
+ * 0 = the walk ends here (END_BLOCK or an error the count walk has already reported).  Rare, so kept out of line: the walk
+ * loops stay small and keep their registers. */
+constexpr uint32_t WG_LIT = 1u << 17;
+__device__ __noinline__ uint32_t walk_general_token(const ParShared &sh, uint32_t pos)
 {
-    pk_store4(k.p, (uint32_t)k.acc);
-    k.p += 4;
-    k.acc >>= 32;
-    k.fill -= 4u;
-}
-__device__ __forceinline__ void pk_put(OutPacker &k, uint32_t b)
-{
-    k.acc |= (unsigned long long)b << (8u * k.fill);
-    k.fill++;
-    if (k.fill >= 4u) pk_flush_word(k);
-}
-__device__ __forceinline__ void pk_finish(OutPacker &k)
-{
-    for (uint32_t j = 0; j < k.fill; j++) k.p[j] = (uint8_t)(k.acc >> (8u * j));
-    k.p += k.fill;
-    k.acc = 0;
-    k.fill = 0;
-}
-/* `n` copies of byte b (a distance-1 match) */
-__device__ __forceinline__ void pk_run(OutPacker &k, uint32_t b, uint32_t n)
-{
-    const unsigned long long pat = 0x0101010101010101ull * (unsigned long long)b;
-    if (n >= 48u) {
-        /* long run: byte-feed up to a 16-byte boundary, then whole 16-byte stores */
-        while ((((uintptr_t)k.p + k.fill) & 15u) != 0u) { pk_put(k, b); n--; }
-        pk_finish(k);
-        const uint32_t w = (uint32_t)pat;
-        const uint4 v = make_uint4(w, w, w, w);
-        for (; n >= 16u; n -= 16u) { *reinterpret_cast<uint4 *>(k.p) = v; k.p += 16; }
-    }
-    while (n) {
-        const uint32_t room = 8u - k.fill; /* fill < 4 here, so room >= 5 */
-        const uint32_t take = n < room ? n : room;
-        const unsigned long long m = take >= 8u ? ~0ull : ((1ull << (8u * take)) - 1ull);
-        k.acc |= (pat & m) << (8u * k.fill);
-        k.fill += take;
-        n -= take;
-        while (k.fill >= 4u) pk_flush_word(k);
-    }
+    auto peek = [&](uint32_t p) -> uint32_t { /* >= 32 bits from window bit p */
+        const uint32_t i = p >> 5;
+        return (uint32_t)((((unsigned long long)sh.win[i + 1] << 32) | sh.win[i]) >> (p & 31u));
+    };
+    const uint32_t d = huff_decode_lit(sh, peek(pos));
+    if (d == 0xffffffffu) return 0u;
+    const uint32_t l = d >> 16, sym = d & 0xffffu;
+    if (sym < 256u) return l | (1u << 8) | WG_LIT | (sym << 18);
+    if (sym == 256u) return 0u;
+    const int lc = (int)sym - 257;
+    if (lc >= 29) return 0u;
+    const uint32_t xb = (uint32_t)len_extra_bits(lc);
+    const uint32_t ml = base_len_of(lc) + (peek(pos + l) & ((1u << xb) - 1u));
+    const uint32_t dd = huff_decode_dist(sh.dist, peek(pos + l + xb));
+    if (dd == 0xffffffffu) return 0u;
+    const uint32_t dl = dd >> 16, dc = dd & 0xffffu;
+    const uint32_t dxb = dc < 4u ? 0u : (dc >> 1) - 1u;
+    return (l + xb + dl + dxb) | (ml << 8);
 }
 
-/* P4 walk of one lane: decode its piece from `start` and write the plane bytes at `out` */
+/* P4 walk of one lane: decode its piece from `start` and write the plane bytes at `out`.  Every token is "n copies of the
+ * last literal" (n = 1 and a new last literal for a literal token, 3..258 for a distance-1 match), appended four bytes at a
+ * time into a 64-bit register and stored with (generally unaligned) dword stores -- gfx9 global memory takes them.  One code
+ * path for literals and runs: the lanes of a wave, which hold different token kinds in every iteration, do not serialise
+ * through two branches. */
 __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, uint32_t limit, uint8_t *out, uint32_t last)
 {
     uint32_t pos = start;
@@ -499,40 +487,51 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
     uint64_t buf = ((uint64_t)sh.win[wi] | ((uint64_t)sh.win[wi + 1] << 32)) >> (pos & 31u);
     int nb = 64 - (int)(pos & 31u);
     wi += 2;
-    OutPacker pk;
-    pk_init(pk, out);
+    uint8_t *p = out;            /* where the low byte of acc goes */
+    unsigned long long acc = 0;  /* pending bytes */
+    uint32_t fill = 0;           /* bytes held in acc (< 4 at the top of the loop) */
     while (pos < limit) {
         if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
-        const uint32_t idx = (uint32_t)buf & ((1u << LBITS) - 1u);
-        const uint32_t e = sh.tok[idx];
-        const uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
+        const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
+        uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
         if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) {
-            if (n == 1u) { last = (e >> TOK_SYM_SHIFT) & 0xffu; pk_put(pk, last); }
-            else pk_run(pk, last, n);
+            if (n == 1u) last = (e >> TOK_SYM_SHIFT) & 0xffu;
             buf >>= t; nb -= (int)t; pos += t;
-            continue;
+        } else {
+            const uint32_t g = walk_general_token(sh, pos);
+            if (g == 0u) break;
+            t = g & 0xffu; n = (g >> 8) & 0x1ffu;
+            if (g & WG_LIT) last = (g >> 18) & 0xffu;
+            pos += t;
+            wi = pos >> 5;
+            buf = ((uint64_t)sh.win[wi] | ((uint64_t)sh.win[wi + 1] << 32)) >> (pos & 31u);
+            nb = 64 - (int)(pos & 31u);
+            wi += 2;
         }
-        const uint32_t d = huff_decode_lit(sh, (uint32_t)buf);
-        if (d == 0xffffffffu) break;
-        const int l = (int)(d >> 16);
-        const uint32_t sym = d & 0xffffu;
-        buf >>= l; nb -= l; pos += (uint32_t)l;
-        if (sym < 256u) { last = sym; pk_put(pk, sym); }
-        else if (sym == 256u) break;
-        else {
-            const int lc = (int)sym - 257;
-            const int xb = len_extra_bits(lc);
-            const uint32_t ml = base_len_of(lc) + ((uint32_t)buf & ((1u << xb) - 1u));
-            buf >>= xb; nb -= xb; pos += (uint32_t)xb;
-            if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
-            const uint32_t dd = huff_decode_dist(sh.dist, (uint32_t)buf);
-            const int dl = (int)(dd >> 16), dc = (int)(dd & 0xffffu);
-            const int dxb = dc < 4 ? 0 : (dc >> 1) - 1;
-            buf >>= (dl + dxb); nb -= dl + dxb; pos += (uint32_t)(dl + dxb);
-            pk_run(pk, last, ml);
+        const uint32_t pat = last * 0x01010101u;
+        if (n >= 48u) {
+            /* long run: bytes up to a 16-byte boundary, then whole 16-byte stores; the rest below */
+            uint32_t head = (16u - (uint32_t)(((uintptr_t)p + fill) & 15u)) & 15u;
+            n -= head;
+            while (head) {
+                const uint32_t take = head < 4u ? head : 4u;
+                acc |= (unsigned long long)(pat & (take == 4u ? 0xffffffffu : ((1u << (8u * take)) - 1u))) << (8u * fill);
+                fill += take; head -= take;
+                if (fill >= 4u) { pk_store4(p, (uint32_t)acc); p += 4; acc >>= 32; fill -= 4u; }
+            }
+            for (uint32_t j = 0; j < fill; j++) p[j] = (uint8_t)(acc >> (8u * j));
+            p += fill; acc = 0; fill = 0;
+            const uint4 v = make_uint4(pat, pat, pat, pat);
+            for (; n >= 16u; n -= 16u) { *reinterpret_cast<uint4 *>(p) = v; p += 16; }
+        }
+        while (n) {
+            const uint32_t take = n < 4u ? n : 4u;
+            acc |= (unsigned long long)(pat & (take == 4u ? 0xffffffffu : ((1u << (8u * take)) - 1u))) << (8u * fill);
+            fill += take; n -= take;
+            if (fill >= 4u) { pk_store4(p, (uint32_t)acc); p += 4; acc >>= 32; fill -= 4u; }
         }
     }
-    pk_finish(pk);
+    for (uint32_t j = 0; j < fill; j++) p[j] = (uint8_t)(acc >> (8u * j));
 }
 
 
@@ -880,14 +879,18 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
     PHASE(15);
     huff_build<0, 9>(sh.dist, sh.lens + sh.nlen, (int)sh.ndist, tid, sh.dist.lut, DBITS);
     PHASE(16);
+    if (tid == 0) sh.complete = 1; /* (the last barrier of huff_build is behind us; the one below publishes the verdict) */
+    bool anyzero = false;
     for (int i = tid; i < (1 << LBITS); i += PT) {
         uint32_t nby;
         const uint32_t t = fast_token_entry(sh, (uint32_t)i, &nby);
         sh.tok[i] |= t | (nby << 8);
+        anyzero |= t == 0u;
     }
     /* longest token of this block: bounds the exit-function domain */
     if (tid == 0) { sh.dmax = 0; sh.maxtok = 1; sh.mintok = 15; }
     __syncthreads();
+    if (anyzero) sh.complete = 0;
     if ((uint32_t)tid < sh.ndist) {
         const uint32_t dl = sh.lens[sh.nlen + tid];
         if (dl) atomicMax(&sh.dmax, dl + ((uint32_t)tid < 4u ? 0u : ((uint32_t)tid >> 1) - 1u));
@@ -916,8 +919,13 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         uint32_t entry;
         {
             /* P1: exit values of my piece -> my column of sh.ring (rows 0..23 = exit function) */
-            if (sh.mintok >= 4u) piece_exit_lds<true>(sh, (uint32_t)tid, wlead);
-            else piece_exit_lds<false>(sh, (uint32_t)tid, wlead);
+            if (sh.complete) {
+                if (sh.mintok >= 4u) piece_exit_lds<true, true>(sh, (uint32_t)tid, wlead);
+                else piece_exit_lds<false, true>(sh, (uint32_t)tid, wlead);
+            } else {
+                if (sh.mintok >= 4u) piece_exit_lds<true, false>(sh, (uint32_t)tid, wlead);
+                else piece_exit_lds<false, false>(sh, (uint32_t)tid, wlead);
+            }
             PHASE(2);
             /* P2: resolve every piece's entry offset.  Composing whole functions (24 look-ups each) in a scan
              * is 24x redundant; instead the wave walks its 64 functions as a chain.  Pass 1: lane k < 24 of each
@@ -959,7 +967,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         /* P3: walk from the true entry, counting */
         SubResult r;
         if (start != POS_INVALID) r = count_walk<true>(sh, start, limit);
-        else { r.land = POS_INVALID; r.nout = 0; r.flags = (entry == X_ERR) ? F_ERR : 0; r.lastlit = 0; }
+        else { r.land = POS_INVALID; r.nout = 0; r.flags = 0; r.lastlit = 0; } /* behind END_BLOCK or behind a token the walk of an earlier lane flags */
         PHASE(4);
         /* first lane that ended the block (or failed); lanes after it are inactive */
         const uint32_t e = block_min_pt((r.flags & (F_EOB | F_ERR)) ? (uint32_t)tid : 0xffffffffu, sh.scan_a);
