@@ -769,13 +769,86 @@ __device__ __forceinline__ void packer_finish(LanePacker &p)
     if (p.nacc > 0) atomicOr(&p.stage[p.word], (uint32_t)p.acc);
 }
 
-__global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes, uint64_t nfloats, const TileInfo *__restrict__ tinfo,
+#ifndef EMIT_WAVES
+#define EMIT_WAVES 4 /* 123 VGPRs, no spills; with 9.1 KB of LDS per wave 16-17 waves fit a CU (measured: 5 is slower, it spills) */
+#endif
+#define OPAQUE4(x, q) asm volatile("" : "+v"((x)[4 * (q)]), "+v"((x)[4 * (q) + 1]), "+v"((x)[4 * (q) + 2]), "+v"((x)[4 * (q) + 3]))
+
+/* byte j (0..15, run-time) of the four words of a row quarter */
+__device__ __forceinline__ uint32_t quarter_byte(const uint32_t wv[4], int j)
+{
+    const uint64_t lo = (uint64_t)wv[0] | ((uint64_t)wv[1] << 32), hi = (uint64_t)wv[2] | ((uint64_t)wv[3] << 32);
+    return (uint32_t)(((j & 8) ? hi : lo) >> (8 * (j & 7))) & 0xffu;
+}
+
+/* pass A of one row quarter (16 positions in the words wv): bits the lane's literals of this quarter produce */
+__device__ __forceinline__ uint32_t quarter_literal_bits(const uint32_t *lut, const uint32_t wv[4], uint32_t Lg)
+{
+    uint32_t bits = 0;
+    if (__ballot(Lg != 0xffffu) == 0ull) { /* everybody has 16 literals: no per-position tests */
+#pragma unroll
+        for (int j = 0; j < 16; j++) bits += lut[(wv[j >> 2] >> (8 * (j & 3))) & 0xffu] >> 16;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t e = lut[(wv[j >> 2] >> (8 * (j & 3))) & 0xffu];
+            bits += ((Lg >> j) & 1u) ? (e >> 16) : 0u;
+        }
+    }
+    return bits;
+}
+
+/* pass B of one row quarter: append the codes of the symbols that start in it */
+__device__ __forceinline__ void quarter_emit(LanePacker &pk, const uint32_t *lut, const uint32_t wv[4], uint32_t Sg, uint32_t Mg,
+                                             int q, const LaneTile &lt, uint32_t dbits)
+{
+    if (__ballot(Mg != 0u || Sg != 0xffffu) == 0ull) {
+        /* literals only, for every lane (the interior of a coded plane): two codes (<= 15 bits each) are joined in 32 bits
+         * and appended with one 64-bit shift */
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const uint32_t e0 = lut[(wv[j >> 2] >> (8 * (j & 3))) & 0xffu];
+            const uint32_t e1 = lut[(wv[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xffu];
+            const uint32_t n0 = e0 >> 16;
+            packer_put(pk, (e0 & 0xffffu) | ((e1 & 0xffffu) << n0), (int)(n0 + (e1 >> 16)));
+        }
+        return;
+    }
+    /* runs and literals mixed (exponent planes, masked planes): walk the lane's symbols, not its positions -- a match covers
+     * at least three positions, so there are far fewer of them, and the match arithmetic runs once per match instead of once
+     * per position in which any lane of the wave happens to have one */
+    uint32_t rem = Sg;
+    while (__ballot(rem != 0u)) {
+        if (rem) {
+            const int j = __builtin_ctz(rem);
+            rem &= rem - 1u;
+            uint32_t val;
+            int nb;
+            if ((Mg >> j) & 1u) {
+                int xb, xv;
+                const int code = len_code(match_len_at(lt.E, lt.a, lt.nextS, 16 * q + j), &xb, &xv);
+                const uint32_t e = lut[257 + code];
+                const int cl = (int)(e >> 16);
+                val = (e & 0xffffu) | ((uint32_t)xv << cl);
+                nb = cl + xb + (int)dbits;
+            } else {
+                const uint32_t e = lut[quarter_byte(wv, j)];
+                val = e & 0xffffu;
+                nb = (int)(e >> 16);
+            }
+            packer_put(pk, val, nb);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EMIT_WAVES))) void k_emit(const uint8_t *__restrict__ planes, uint64_t nfloats, const TileInfo *__restrict__ tinfo,
                                               const StreamInfo *__restrict__ sinfo, const BlkLay *__restrict__ lay,
                                               const uint32_t *__restrict__ blkstart, const uint32_t *__restrict__ blkcode,
                                               const uint32_t *__restrict__ pairoff, uint8_t *__restrict__ out)
 {
-    /* one wave = one (segment, plane): no workgroup barriers, light planes retire early */
-    __shared__ __attribute__((aligned(16))) uint8_t lds[PLANE_LDS];
+    /* one wave = one (segment, plane): no workgroup barriers, light planes retire early.  The lane's 64 plane bytes stay in
+     * registers for both passes: an LDS copy of the tile costs 5 KB per wave and with it a third of the occupancy, and this
+     * kernel waits on LDS look-ups, so it is as fast as the number of waves that hide them. */
     __shared__ __attribute__((aligned(16))) uint32_t stage[STAGE_WORDS];
     __shared__ uint32_t lut[HROW];
     const uint32_t g = blockIdx.x, c = blockIdx.y;
@@ -793,7 +866,7 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
 
     uint32_t curBlk = 0xffffffffu;
     uint32_t cur = 0;        /* stream bit offset where the next symbol of the current block goes */
-    int mode = -1;           /* 0 stored, 1 static, 2 dynamic, 3 raw stream */
+    int mode = -1;           /* 0 stored, 1 static, 2 dynamic */
     uint32_t blkEnd = 0;     /* position where the current block ends */
     uint32_t dbits = 0;      /* distance-code bits per match (1 dynamic, 5 static) */
 
@@ -801,7 +874,6 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
         const uint32_t t0 = g * SEG + ti * TILE;
         if (t0 >= n) break;
         const int len = (int)((n - t0) < (uint32_t)TILE ? (n - t0) : (uint32_t)TILE);
-        __builtin_amdgcn_wave_barrier(); /* the previous tile's readers are done */
         uint32_t x[16];
         load_plane_row(pl, t0, len, lane, x);
         if (si.raw) {
@@ -817,41 +889,14 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
                     __builtin_memcpy(dst + 16 * k, &v, 16);
                 }
             } else {
-                for (int i = 0; i < mine; i++) dst[i] = (uint8_t)(x[i >> 2] >> (8 * (i & 3)));
+                for (int i = 0; i < mine; i++) dst[i] = pl[t0 + 64u * (uint32_t)lane + (uint32_t)i];
             }
             continue;
         }
-        {
-            /* the tile also goes to LDS: the verbatim path reads it byte-wise across lanes, the coded path re-reads
-             * its own row in quarters to keep the packer's register footprint small */
-            uint4 *row = reinterpret_cast<uint4 *>(lds + lane * ROWPAD);
-#pragma unroll
-            for (int k = 0; k < 4; k++) row[k] = make_uint4(x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const uint8_t *plane = lds;
         const TileInfo tinf = tinfo[(size_t)s * TPS + (t0 / TILE)];
-        /* a RAW plane is copied verbatim: no run analysis (wave-uniform) */
-        LaneTile lt;
-        LaneCls cls;
-        if (!si.raw) {
-            lt = analyse_lane(x, lane, len, tinf.B, tinf.F);
-            cls = classify_lane(lt.E, lt.a, lt.prevS, lt.nextS);
-        } else {
-            lt.E = 0; lt.V = valid_mask(len, lane); lt.a = 64 * lane; lt.prevS = 0; lt.nextS = 0;
-            cls.S = 0; cls.M = 0;
-        }
-
-        if (si.raw) {
-            /* RAW plane (zip.c:184-190): the payload is the plane bytes themselves */
-            if (mode != 3) {
-                mode = 3;
-                for (int i = lane; i < 256; i += 64) lut[i] = (uint32_t)i | (8u << 16);
-                blkEnd = n;
-                __builtin_amdgcn_wave_barrier();
-            }
-            cur = 8u * t0;
-        } else if (curBlk == 0xffffffffu) {
+        const LaneTile lt = analyse_lane(x, lane, len, tinf.B, tinf.F);
+        const LaneCls cls = classify_lane(lt.E, lt.a, lt.prevS, lt.nextS);
+        if (curBlk == 0xffffffffu) {
             curBlk = tinf.P / BLK_SYMS;
             if (bstart[curBlk] > t0) curBlk--; /* the tile starts inside the previous block's last match */
             mode = -1;
@@ -860,63 +905,51 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
         /* a tile may straddle one block boundary: process [part 0 | part 1] */
         int pos0 = 0; /* tile-relative start of the part */
         for (int part = 0; part < 2 && pos0 < len; part++) {
-            if (!si.raw) {
-                if (mode < 0 || t0 + (uint32_t)pos0 >= blkEnd) {
-                    if (mode >= 0) curBlk++;
-                    const BlkLay L = blay[curBlk];
-                    mode = (int)L.btype;
-                    blkEnd = bstart[curBlk + 1];
-                    if (mode == 0) {
-                        for (int i = lane; i < 256; i += 64) lut[i] = (uint32_t)i | (8u << 16);
-                        cur = L.databit + 8u * (t0 + (uint32_t)pos0 - bstart[curBlk]);
+            if (mode < 0 || t0 + (uint32_t)pos0 >= blkEnd) {
+                if (mode >= 0) curBlk++;
+                const BlkLay L = blay[curBlk];
+                mode = (int)L.btype;
+                blkEnd = bstart[curBlk + 1];
+                if (mode == 0) cur = L.databit + 8u * (t0 + (uint32_t)pos0 - bstart[curBlk]);
+                else {
+                    __builtin_amdgcn_wave_barrier(); /* the previous block's table readers are done */
+                    if (mode == 2) {
+                        const uint32_t *code = blkcode + ((size_t)s * MAXBLK + curBlk) * HROW;
+                        for (int i = lane; i < 286; i += 64) lut[i] = code[i];
+                        dbits = 1;
                     } else {
-                        if (mode == 2) {
-                            const uint32_t *code = blkcode + ((size_t)s * MAXBLK + curBlk) * HROW;
-                            for (int i = lane; i < 286; i += 64) lut[i] = code[i];
-                            dbits = 1;
-                        } else {
-                            for (int i = lane; i < 286; i += 64) {
-                                int l;
-                                const uint32_t cd = static_lcode(i, &l);
-                                lut[i] = cd | ((uint32_t)l << 16);
-                            }
-                            dbits = 5;
+                        for (int i = lane; i < 286; i += 64) {
+                            int l;
+                            const uint32_t cd = static_lcode(i, &l);
+                            lut[i] = cd | ((uint32_t)l << 16);
                         }
-                        cur = pairoff[(size_t)s * MAXPAIR + (g + curBlk)];
+                        dbits = 5;
                     }
+                    cur = pairoff[(size_t)s * MAXPAIR + (g + curBlk)];
                     __builtin_amdgcn_wave_barrier(); /* lut visible to the whole wave */
                 }
             }
             int pos1 = len; /* tile-relative end of the part */
             if (blkEnd < t0 + (uint32_t)len) pos1 = (int)(blkEnd - t0);
-            /* lane-relative part mask */
-            const int lo = pos0 - lt.a, hi = pos1 - lt.a;
-            const uint64_t mlo = lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
-            const uint64_t mhi = hi >= 64 ? ~0ull : (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
-            const uint64_t pm = mlo & mhi & lt.V;
-            const bool bytes_mode = (mode == 0 || mode == 3);
-            const uint64_t S = bytes_mode ? pm : (cls.S & pm);
-            const uint64_t M = bytes_mode ? 0ull : (cls.M & pm);
 
-            if (bytes_mode) {
-                /* RAW plane / STORED block: plane bytes [pos0, pos1) go out verbatim at a byte-aligned
-                 * address.  The wave assembles aligned output dwords straight from the LDS plane tile
-                 * (4 byte reads each); only a partial first / last dword is merged with atomicOr. */
+            if (mode == 0) {
+                /* STORED block: plane bytes [pos0, pos1) go out verbatim at a byte-aligned address.  The wave assembles
+                 * aligned output dwords from the plane in HBM (the tile was just read: cache hits; stored blocks are only the
+                 * first and last block of an incompressible plane); a partial first / last dword is merged with atomicOr. */
                 const uint32_t nbytes = (uint32_t)(pos1 - pos0);
                 const uint64_t dg = si.payoff + (cur >> 3);       /* cur is a multiple of 8 here */
                 const uint32_t mis = (uint32_t)(dg & 3u);
                 const uint64_t w0 = dg >> 2;
                 const uint32_t nwords = (mis + nbytes + 3u) >> 2;
+                const uint8_t *src = pl + t0 + (uint32_t)pos0;
                 for (uint32_t k = lane; k < nwords; k += 64) {
                     uint32_t v = 0;
                     bool full = true;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int rel = (int)(4u * k + (uint32_t)j) - (int)mis; /* byte of the part */
-                        if (rel >= 0 && rel < (int)nbytes) {
-                            const uint32_t pp = (uint32_t)pos0 + (uint32_t)rel;
-                            v |= (uint32_t)plane[(pp >> 6) * ROWPAD + (pp & 63u)] << (8 * j);
-                        } else full = false;
+                        if (rel >= 0 && rel < (int)nbytes) v |= (uint32_t)src[rel] << (8 * j);
+                        else full = false;
                     }
                     if (full) out32[w0 + k] = v;
                     else if (v) atomicOr(&out32[w0 + k], v);
@@ -925,32 +958,25 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
                 pos0 = pos1;
                 continue;
             }
+            /* lane-relative part mask */
+            const int lo = pos0 - lt.a, hi = pos1 - lt.a;
+            const uint64_t mlo = lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+            const uint64_t mhi = hi >= 64 ? ~0ull : (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
+            const uint64_t pm = mlo & mhi & lt.V;
+            const uint64_t S = cls.S & pm, M = cls.M & pm;
 
-            /* pass A: bits produced by this lane.  The 64 table reads are independent (unrolled, bytes
-             * come from registers), so their LDS latency overlaps; matches are rare and handled apart. */
+            /* pass A: bits produced by this lane.  The table reads of a quarter are independent (unrolled, bytes come from
+             * registers), so their LDS latency overlaps; matches are rare and handled apart. */
             if (__ballot(S != 0ull) == 0ull) { pos0 = pos1; continue; } /* no symbol starts in this part (inside long runs) */
             uint32_t lbits = 0;
             {
                 const uint64_t L = S & ~M;
-                const uint4 *row128 = reinterpret_cast<const uint4 *>(plane + lane * ROWPAD);
-#pragma unroll 1
-                for (int g = 0; g < 4; g++) { /* 16 positions per step: bounded register use, 16 reads in flight */
-                    const uint32_t Lg = (uint32_t)(L >> (16 * g)) & 0xffffu;
-                    const unsigned long long some = __ballot(Lg != 0u), notall = __ballot(Lg != 0xffffu);
-                    if (some == 0ull) continue; /* wave-uniform: nobody has a literal in this quarter */
-                    const uint4 rw = row128[g];
-                    const uint32_t wv[4] = {rw.x, rw.y, rw.z, rw.w};
-                    if (notall == 0ull) { /* everybody has 16 literals: no per-position tests */
 #pragma unroll
-                        for (int j = 0; j < 16; j++) lbits += lut[(wv[j >> 2] >> (8 * (j & 3))) & 0xffu] >> 16;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 16; j++) {
-                            const uint32_t byte = (wv[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                            const uint32_t e = lut[byte];
-                            lbits += ((Lg >> j) & 1u) ? (e >> 16) : 0u;
-                        }
-                    }
+                for (int q = 0; q < 4; q++) { /* 16 positions per step; unrolled, so that the quarter's words are registers */
+                    const uint32_t Lg = (uint32_t)(L >> (16 * q)) & 0xffffu;
+                    if (__ballot(Lg != 0u) == 0ull) continue; /* wave-uniform: nobody has a literal in this quarter */
+                    OPAQUE4(x, q); /* or the byte extraction of all four quarters is hoisted out of the part loop: 64 registers */
+                    lbits += quarter_literal_bits(lut, &x[4 * q], Lg);
                 }
                 uint64_t m = M;
                 while (m) {
@@ -971,56 +997,12 @@ __global__ __launch_bounds__(64) void k_emit(const uint8_t *__restrict__ planes,
                 __builtin_amdgcn_wave_barrier();
                 LanePacker pk;
                 packer_init(pk, stage, lead + lofs);
-                {
-                    const uint4 *row128 = reinterpret_cast<const uint4 *>(plane + lane * ROWPAD);
-#pragma unroll 1
-                    for (int g = 0; g < 4; g++) {
-                        const uint32_t Sg = (uint32_t)(S >> (16 * g)) & 0xffffu, Mg = (uint32_t)(M >> (16 * g)) & 0xffffu;
-                        if (__ballot(Sg != 0u) == 0ull) continue; /* wave-uniform: no symbol starts in this quarter */
-                        const uint4 rw = row128[g];
-                        const uint32_t wv[4] = {rw.x, rw.y, rw.z, rw.w};
-                        if (__ballot(Mg != 0u || Sg != 0xffffu) == 0ull) {
-                            /* literals only, for every lane (the interior of a coded plane): two codes (<= 15 bits
-                             * each) are joined in 32 bits and appended with one 64-bit shift */
 #pragma unroll
-                            for (int j = 0; j < 16; j += 2) {
-                                const uint32_t e0 = lut[(wv[j >> 2] >> (8 * (j & 3))) & 0xffu];
-                                const uint32_t e1 = lut[(wv[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xffu];
-                                const uint32_t n0 = e0 >> 16;
-                                packer_put(pk, (e0 & 0xffffu) | ((e1 & 0xffffu) << n0), (int)(n0 + (e1 >> 16)));
-                            }
-                            continue;
-                        }
-                        /* runs and literals mixed (exponent planes, masked planes): walk the lane's symbols, not its
-                         * positions -- a match covers at least three positions, so there are far fewer of them, and
-                         * the match arithmetic runs once per match instead of once per position in which any lane
-                         * of the wave happens to have one */
-                        {
-                            uint32_t rem = Sg;
-                            const uint8_t *rowb = plane + lane * ROWPAD + 16 * g;
-                            while (__ballot(rem != 0u)) {
-                                if (rem) {
-                                    const int j = __builtin_ctz(rem);
-                                    rem &= rem - 1u;
-                                    uint32_t val;
-                                    int nb;
-                                    if ((Mg >> j) & 1u) {
-                                        int xb, xv;
-                                        const int code = len_code(match_len_at(lt.E, lt.a, lt.nextS, 16 * g + j), &xb, &xv);
-                                        const uint32_t e = lut[257 + code];
-                                        const int cl = (int)(e >> 16);
-                                        val = (e & 0xffffu) | ((uint32_t)xv << cl);
-                                        nb = cl + xb + (int)dbits;
-                                    } else {
-                                        const uint32_t e = lut[rowb[j]];
-                                        val = e & 0xffffu;
-                                        nb = (int)(e >> 16);
-                                    }
-                                    packer_put(pk, val, nb);
-                                }
-                            }
-                        }
-                    }
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t Sg = (uint32_t)(S >> (16 * q)) & 0xffffu, Mg = (uint32_t)(M >> (16 * q)) & 0xffffu;
+                    if (__ballot(Sg != 0u) == 0ull) continue; /* wave-uniform: no symbol starts in this quarter */
+                    OPAQUE4(x, q);
+                    quarter_emit(pk, lut, &x[4 * q], Sg, Mg, q, lt, dbits);
                 }
                 packer_finish(pk);
                 __builtin_amdgcn_wave_barrier();
