@@ -34,6 +34,7 @@ struct mrcz_ctx {
     hipStream_t lane_stream[MAX_LANES]; /* ... the lanes of a compress batch (see mrcz_compress_chunks); [0] = stream */
     hipEvent_t ev_start, ev_cont, ev_done[MAX_LANES];
     hipEvent_t ev_stream[MAX_LANES]; /* lane l's summary + histogram passes are done */
+    uint32_t split_pct;            /* two lanes: share of a batch's chunks (per cent) the first lane takes; MRCZ_SPLIT overrides it */
     int stagger;                   /* lanes start one after the other (each once the previous one's streaming passes are done), so that
                                     * their Huffman kernels -- one tree's latency long, nearly idle machine -- run under the other lanes'
                                     * bandwidth-bound passes instead of side by side */
@@ -160,6 +161,8 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     for (int l = 0; l < MAX_LANES && e == hipSuccess; l++) e = hipEventCreateWithFlags(&ctx->ev_stream[l], hipEventDisableTiming);
     ctx->stagger = 1;
     ctx->huff_ht = 48;
+    ctx->split_pct = 50;
+    if (const char *ev = getenv("MRCZ_SPLIT")) { const int v = atoi(ev); if (v >= 5 && v <= 95) ctx->split_pct = (uint32_t)v; }
     if (const char *ev = getenv("MRCZ_STAGGER")) ctx->stagger = atoi(ev) ? 1 : 0;
     if (const char *ev = getenv("MRCZ_HT")) { const int v = atoi(ev); if (v == 16 || v == 32 || v == 48) ctx->huff_ht = v; }
     t_streams = wall_now();
@@ -344,9 +347,10 @@ static int compress_lane(mrcz_ctx *ctx, hipStream_t lstream, int phase, int slot
         LAUNCH("k_block_reduce", k_block_reduce, dim3(MAXBLK, ns), dim3(64), tinfo, sinfo, pairhist, blkfreq);
         LAUNCH("k_block_index", k_block_index, dim3(1), dim3(256), sinfo, ns, blkbase);
         if (ctx->stagger) HIPCHK(hipEventRecord(ctx->ev_stream[slot], lstream), "event"); /* this lane's streaming passes are done: the next lane may start */
-        if (ctx->huff_ht == 16) LAUNCH("k_huffman", k_huffman<16>, dim3((ns * MAXBLK + 15) / 16), dim3(16), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta);
-        else if (ctx->huff_ht == 32) LAUNCH("k_huffman", k_huffman<32>, dim3((ns * MAXBLK + 31) / 32), dim3(32), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta);
-        else LAUNCH("k_huffman", k_huffman<48>, dim3((ns * MAXBLK + 47) / 48), dim3(48), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta);
+        unsigned long long *hdbg = ctx->phase_profile == 3 ? ctx->dbgphase : (unsigned long long *)NULL; /* developer tool */
+        if (ctx->huff_ht == 16) LAUNCH("k_huffman", k_huffman<16>, dim3((ns * MAXBLK + 15) / 16), dim3(16), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
+        else if (ctx->huff_ht == 32) LAUNCH("k_huffman", k_huffman<32>, dim3((ns * MAXBLK + 31) / 32), dim3(32), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
+        else LAUNCH("k_huffman", k_huffman<48>, dim3((ns * MAXBLK + 47) / 48), dim3(48), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
 
         LAUNCH("k_stream_layout", k_stream_layout, dim3(ns), dim3(64), sinfo, meta, blkstart, slideq, lay);
         LAUNCH("k_pair_bits", k_pair_bits, dim3(SPS, ns), dim3(64), sinfo, lay, pairhist, blkcode, tinfo, pairbits);
@@ -390,12 +394,11 @@ static int compress_enqueue(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats,
      * on everything stays on one stream. */
     bool cont_pending = false; /* ev_cont = the last layout step, recorded on a lane other than the next one */
     /* Workspace rows are reused by every batch, and nothing but the layout chain orders the lane streams.  A row must
-     * therefore always be touched by the SAME stream: lane l owns the fixed row range that starts at chunk row l * pc
-     * (pc = rows per lane for the context's lane count), whatever the size of the batch.  Where the lane count changes
-     * between two batches (the last, short batch of a call runs as one lane) the row ownership changes too, and every
-     * lane stream first waits for all of the previous batch. */
-    const uint32_t pc = (ctx->max_chunks + ctx->lanes - 1u) / ctx->lanes;
-    uint32_t prev_lanes = 0;
+     * therefore always be touched by the SAME stream.  A chunk's rows are its place in the batch, and full batches are cut
+     * into lanes at the same places, so lane l meets the rows it had in the batch before.  Where the cut moves between
+     * two batches (the last, short batch of a call) the row ownership changes too, and every lane stream first waits
+     * for all of the previous batch. */
+    uint32_t prev_lanes = 0, prev_lc0[MAX_LANES + 1] = {0};
     int stream_pending = -1; /* lane whose ev_stream the next lane's first pass waits for */
     for (uint64_t c0 = 0; c0 < nchunks; c0 += ctx->max_chunks) {
         const uint32_t nb = (uint32_t)((nchunks - c0) < ctx->max_chunks ? (nchunks - c0) : ctx->max_chunks);
@@ -404,15 +407,23 @@ static int compress_enqueue(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats,
         const uint64_t bfl = (nfloats - c0 * CHK) < (uint64_t)nb * CHK ? (nfloats - c0 * CHK) : (uint64_t)nb * CHK;
         ctx->last_streams = 4u * nb;
         ctx->last_nlanes = nlanes;
-        if (prev_lanes && prev_lanes != nlanes) {
+        uint32_t lc0[MAX_LANES + 1]; /* first chunk (inside the batch) of every lane */
+        for (uint32_t l = 0; l <= nlanes; l++) lc0[l] = (uint32_t)(((uint64_t)nb * l) / nlanes);
+        if (nlanes == 2u) {
+            lc0[1] = (uint32_t)(((uint64_t)nb * ctx->split_pct + 50u) / 100u);
+            if (lc0[1] < 1u) lc0[1] = 1u;
+            if (lc0[1] > nb - 1u) lc0[1] = nb - 1u;
+        }
+        bool same_rows = prev_lanes == nlanes;
+        for (uint32_t l = 0; same_rows && l < nlanes; l++) same_rows = prev_lc0[l] == lc0[l];
+        if (prev_lanes && !same_rows) {
             for (uint32_t l = 0; l < prev_lanes; l++) HIPCHK(hipEventRecord(ctx->ev_done[l], ctx->lane_stream[l]), "event");
             for (uint32_t l = 0; l < nlanes; l++)
                 for (uint32_t k = 0; k < prev_lanes; k++)
                     if (k != l) HIPCHK(hipStreamWaitEvent(ctx->lane_stream[l], ctx->ev_done[k], 0), "wait");
         }
         prev_lanes = nlanes;
-        uint32_t lc0[MAX_LANES + 1]; /* first chunk (inside the batch) of every lane */
-        for (uint32_t l = 0; l <= nlanes; l++) lc0[l] = (uint32_t)(((uint64_t)nb * l) / nlanes);
+        for (uint32_t l = 0; l <= nlanes; l++) prev_lc0[l] = lc0[l];
         for (int phase = 0; phase < 3; phase++) {
             for (uint32_t l = 0; l < nlanes; l++) {
                 const uint32_t cb = lc0[l], nbl = lc0[l + 1] - lc0[l];
@@ -429,7 +440,7 @@ static int compress_enqueue(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats,
                     if (stream_pending >= 0 && stream_pending != (int)l) HIPCHK(hipStreamWaitEvent(st, ctx->ev_stream[stream_pending], 0), "wait");
                     stream_pending = (int)l;
                 }
-                const uint32_t row0 = nlanes == 1u ? 0u : 4u * l * pc; /* first workspace row (stream slot) of this lane */
+                const uint32_t row0 = 4u * cb; /* first workspace row (stream slot) of this lane: a chunk's rows are its place in the batch */
                 ctx->last_lc0[l] = cb; ctx->last_row0[l] = row0;
                 if (int rc = compress_lane(ctx, st, phase, (int)l, row0, in + c0 * CHK + f0, bfll, nbl, mask, fstart, out, int_mode)) return rc;
                 if (phase == 1) {
@@ -792,6 +803,7 @@ extern "C" int mrcz_debug_inflate_phases(mrcz_ctx_t *ctx, int enable, uint32_t s
 {
     if (!ctx) return MRCZ_EINVAL;
     ctx->phase_profile = enable;
+    if (enable == 3 && !out && hipMemset(ctx->dbgphase, 0, 40 * sizeof(unsigned long long)) != hipSuccess) return MRCZ_EHIP; /* 3 = k_huffman's phase clocks */
     if (out) {
         if (stream >= 8u * ctx->max_chunks) return MRCZ_EINVAL;
         if (hipMemcpy(out, ctx->dbgphase + (size_t)stream * 20, 20 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return MRCZ_EHIP;

@@ -18,7 +18,7 @@
 
 namespace mrcz {
 
-/* HT = trees (threads) per workgroup, a template parameter: 1.5 KB of LDS per tree.  48 (72 KB, two workgroups per CU) packs a
+/* HT = trees (threads) per workgroup, a template parameter: 1.5 KB of LDS per tree.  48 (74 KB, two workgroups per CU) packs a
  * wave best; 16 (24 KB) leaves LDS room for the streaming kernels of the other compress lanes that run under the trees. */
 constexpr int LELEMS = 286;
 constexpr int BLELEMS = 19;
@@ -33,8 +33,8 @@ constexpr int HSLOTS = 288;
 template <int HT> struct TreeMem {
     uint32_t heap[HSLOTS * HT];
     uint8_t leaflen[HSLOTS * HT];   /* literal/length code lengths */
-    uint16_t blcount[16 * HT];
-    uint16_t nextcode[16 * HT];
+    uint32_t blcount[16 * HT];      /* 32-bit: counted and handed out with LDS atomics (a return-less ds_add needs no wait) */
+    uint32_t nextcode[16 * HT];
 };
 
 #define HEAP(i) tm.heap[(i) * HT + tid]
@@ -44,7 +44,7 @@ template <int HT> struct TreeMem {
 /* bit-length tree, inside the heap region: heap + merge records in slots 1..19 */
 #define BLFREQ(i) HEAP(32 + (i))
 #define BLLEN(i) HEAP(64 + (i))
-#define BLCODE(i) HEAP(96 + (i))
+#define BLENT(i) HEAP(96 + (i))   /* bit-length code of symbol i | its length << 8: one read per header symbol */
 
 /* zlib's pqdownheap with the value to place passed in a register.  The kernel's time is ONE tree's dependent
  * instruction chain (a wave holds 48 trees and nothing else runs on its SIMD), so the loop is kept to the bare
@@ -69,25 +69,116 @@ template <int HT> __device__ __forceinline__ void sift_down(uint32_t *heap, int 
     hp[a] = v;
 }
 
+/* The merge loop's two sifts per merge start at the root, and a sift costs one LDS round trip plus ~25 instructions per
+ * level (measured: ~290 cycles a level, 62 % of the kernel in this loop).  So the top four levels of the heap (nodes
+ * 1..15) live in registers during the merge loop: a level there is a handful of selects.  Register slots beyond the
+ * end of the heap hold KEY_INF, a key no node has (freq <= 32768), which makes the "has a child" tests of these levels
+ * fall out of the comparisons themselves.  LDS slots 1..15 are dead meanwhile and take merge records as before. */
+constexpr uint32_t KEY_INF = 0xffffffffu;
+struct HeapTop { uint32_t r[16]; }; /* r[1..15]; every index below is a compile-time constant after unrolling */
+
+#define TOP_WRITE(top, lo, a, x)                                                       \
+    do {                                                                               \
+        _Pragma("unroll") for (int i_ = (lo); i_ < 2 * (lo); i_++) (top).r[i_] = ((a) == i_) ? (x) : (top).r[i_]; \
+    } while (0)
+
+template <int HT> __device__ __forceinline__ void sift_root(HeapTop &t, uint32_t *hp /* heap + tid */, int heap_len, uint32_t v)
+{
+    /* level 0: children 2, 3 */
+    uint32_t cj = t.r[2];
+    int a = 2;
+    if (t.r[3] <= (cj | 1023u)) { cj = t.r[3]; a = 3; }
+    if (v <= (cj | 1023u)) { t.r[1] = v; return; }
+    t.r[1] = cj;
+    /* level 1: node a in {2, 3}, children 4..7 */
+    {
+        const bool hi = a == 3;
+        const uint32_t cl = hi ? t.r[6] : t.r[4], cr = hi ? t.r[7] : t.r[5];
+        const bool right = cr <= (cl | 1023u);
+        cj = right ? cr : cl;
+        const bool stop = v <= (cj | 1023u);
+        const uint32_t put = stop ? v : cj;
+        TOP_WRITE(t, 2, a, put);
+        if (stop) return;
+        a = 2 * a + (right ? 1 : 0);
+    }
+    /* level 2: node a in 4..7, children 8..15 */
+    {
+        const uint32_t l01 = (a & 1) ? t.r[10] : t.r[8], l23 = (a & 1) ? t.r[14] : t.r[12];
+        const uint32_t r01 = (a & 1) ? t.r[11] : t.r[9], r23 = (a & 1) ? t.r[15] : t.r[13];
+        const uint32_t cl = (a & 2) ? l23 : l01, cr = (a & 2) ? r23 : r01;
+        const bool right = cr <= (cl | 1023u);
+        cj = right ? cr : cl;
+        const bool stop = v <= (cj | 1023u);
+        const uint32_t put = stop ? v : cj;
+        TOP_WRITE(t, 4, a, put);
+        if (stop) return;
+        a = 2 * a + (right ? 1 : 0);
+    }
+    /* level 3: node a in 8..15 (a register), children 16..31 in LDS; deeper levels as in sift_down */
+    const int lim = heap_len * HT;
+    int aj = 2 * a * HT;
+    if (aj > lim) { TOP_WRITE(t, 8, a, v); return; }
+    {
+        const int aj1 = aj < lim ? aj + HT : aj;
+        cj = hp[aj];
+        const uint32_t cj1 = hp[aj1];
+        if (aj1 != aj && cj1 <= (cj | 1023u)) { aj = aj1; cj = cj1; }
+        const bool stop = v <= (cj | 1023u);
+        const uint32_t put = stop ? v : cj;
+        TOP_WRITE(t, 8, a, put);
+        if (stop) return;
+    }
+    int o = aj;
+    aj <<= 1;
+    while (aj <= lim) {
+        const int aj1 = aj < lim ? aj + HT : aj;
+        cj = hp[aj];
+        const uint32_t cj1 = hp[aj1];
+        if (aj1 != aj && cj1 <= (cj | 1023u)) { aj = aj1; cj = cj1; }
+        if (v <= (cj | 1023u)) break;
+        hp[o] = cj;
+        o = aj;
+        aj <<= 1;
+    }
+    hp[o] = v;
+}
+
 /* heap holds n0 leaf keys (1-based).  Runs zlib's merge loop; returns the number of merges.  Merge i removes
  * n_i then m_i and creates internal node elems + i; its record lands in slot n0 - i. */
-template <int HT> __device__ __forceinline__ int merge_loop(uint32_t *heap, int tid, int n0, int elems)
+template <int HT> __device__ __forceinline__ int merge_loop(uint32_t *heap, int tid, int n0, int elems, uint32_t *merged)
 {
     for (int k = n0 / 2; k >= 1; k--) sift_down<HT>(heap, tid, n0, k, heap[k * HT + tid]);
+    uint32_t *hp = heap + tid;
+    HeapTop t;
+#pragma unroll
+    for (int i = 1; i < 16; i++) t.r[i] = i <= n0 ? hp[i * HT] : KEY_INF;
     int heap_len = n0, it = 0;
+    uint32_t msum = 0;
     do {
-        const uint32_t nkey = heap[1 * HT + tid];
-        const uint32_t lastv = heap[heap_len * HT + tid];
+        const uint32_t nkey = t.r[1];
+        uint32_t lastv;
+        if (heap_len >= 16) lastv = hp[heap_len * HT];
+        else { /* the last node is one of the registers, and its slot leaves the heap */
+            lastv = 0;
+#pragma unroll
+            for (int i = 1; i < 16; i++) {
+                lastv = heap_len == i ? t.r[i] : lastv;
+                t.r[i] = heap_len == i ? KEY_INF : t.r[i];
+            }
+        }
         heap_len--;
-        sift_down<HT>(heap, tid, heap_len, 1, lastv);
-        const uint32_t mkey = heap[1 * HT + tid];
-        heap[(heap_len + 1) * HT + tid] = (nkey & 0x3ffu) | ((mkey & 0x3ffu) << 10);
+        sift_root<HT>(t, hp, heap_len, lastv);
+        const uint32_t mkey = t.r[1];
+        hp[(heap_len + 1) * HT] = (nkey & 0x3ffu) | ((mkey & 0x3ffu) << 10);
         const uint32_t f = (nkey >> 16) + (mkey >> 16);
+        msum += f;
         const uint32_t dn = (nkey >> 10) & 63u, dm = (mkey >> 10) & 63u;
         const uint32_t d = (dn >= dm ? dn : dm) + 1u;
-        sift_down<HT>(heap, tid, heap_len, 1, (f << 16) | (d << 10) | (uint32_t)(elems + it));
+        sift_root<HT>(t, hp, heap_len, (f << 16) | (d << 10) | (uint32_t)(elems + it));
         it++;
     } while (heap_len >= 2);
+    *merged = msum;
     return it;
 }
 /* h-th node in zlib's removal order (n_0, m_0, n_1, m_1, ...) */
@@ -123,6 +214,37 @@ __device__ __forceinline__ void hw_finish(HdrWriter &h)
 
 __device__ __forceinline__ uint32_t bit_reverse(uint32_t code, int len) { return __brev(code) >> (32 - len); }
 
+/* zlib's scan_tree / send_tree walk over a sequence of code lengths (trees.c): one step per symbol, given its length and
+ * the next symbol's (0xffff behind the last).  The step says what the walk does here; both users (counting the bit-length
+ * symbols, writing them) act on it. */
+enum { RS_NONE = 0, RS_LITERALS, RS_REP16, RS_LIT_REP16, RS_REP17, RS_REP18 };
+struct RunScan {
+    int prevlen, count, max_count, min_count;
+    int emit_count; /* RS_LITERALS: how many times the length itself is coded (1..3); REP*: the repeat count the code carries */
+};
+__device__ __forceinline__ void run_scan_init(RunScan &r, int firstlen)
+{
+    r.prevlen = -1; r.count = 0; r.max_count = 7; r.min_count = 4; r.emit_count = 0;
+    if (firstlen == 0) { r.max_count = 138; r.min_count = 3; }
+}
+__device__ __forceinline__ int run_scan_step(RunScan &r, int curlen, int nextlen)
+{
+    int act;
+    if (++r.count < r.max_count && curlen == nextlen) return RS_NONE;
+    if (r.count < r.min_count) { act = RS_LITERALS; r.emit_count = r.count; }
+    else if (curlen != 0) {
+        if (curlen != r.prevlen) { act = RS_LIT_REP16; r.emit_count = r.count - 1; }
+        else { act = RS_REP16; r.emit_count = r.count; }
+    } else if (r.count <= 10) { act = RS_REP17; r.emit_count = r.count; }
+    else { act = RS_REP18; r.emit_count = r.count; }
+    r.count = 0;
+    r.prevlen = curlen;
+    if (nextlen == 0) { r.max_count = 138; r.min_count = 3; }
+    else if (curlen == nextlen) { r.max_count = 6; r.min_count = 3; }
+    else { r.max_count = 7; r.min_count = 4; }
+    return act;
+}
+
 /* blkbase[s] = number of blocks in streams < s (exclusive prefix), blkbase[nstreams] = total */
 __global__ __launch_bounds__(256) void k_block_index(const StreamInfo *__restrict__ sinfo, uint32_t nstreams,
                                                      uint32_t *__restrict__ blkbase)
@@ -154,10 +276,21 @@ __global__ __launch_bounds__(256) void k_block_index(const StreamInfo *__restric
 template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ sinfo, uint32_t nstreams,
                                                 const uint32_t *__restrict__ blkbase, const uint16_t *__restrict__ blkfreq,
                                                 uint32_t *__restrict__ blkcode, uint32_t *__restrict__ blkhdr,
-                                                BlkMeta *__restrict__ meta)
+                                                BlkMeta *__restrict__ meta,
+                                                unsigned long long *__restrict__ dbg /* NULL, or phase clocks: [i] max, [16 + i] sum, [32] trees */)
 {
     __shared__ TreeMem<HT> tm;
     const int tid = threadIdx.x;
+    unsigned long long tp = dbg ? (unsigned long long)clock64() : 0ull;
+#define HPHASE(i)                                                              \
+    do {                                                                       \
+        if (dbg) {                                                             \
+            const unsigned long long now_ = (unsigned long long)clock64();     \
+            atomicMax(&dbg[i], now_ - tp);                                     \
+            atomicAdd(&dbg[16 + (i)], now_ - tp);                              \
+            tp = now_;                                                         \
+        }                                                                      \
+    } while (0)
     /* all-zero code lengths for every tree of the workgroup (one wave: cooperative, before anyone leaves) */
     for (int w = tid; w < HSLOTS * HT / 4; w += HT) reinterpret_cast<uint32_t *>(tm.leaflen)[w] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -175,48 +308,67 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
     const uint4 *fq8 = reinterpret_cast<const uint4 *>(fq); /* 8 frequencies per load */
     uint32_t *code_out = blkcode + ((size_t)s * MAXBLK + b) * HROW;
 
-    /* ---------------- literal/length tree ---------------- */
+    /* ---------------- literal/length tree ----------------
+     * The thread is alone on its dependent chain (48 trees a wave, one wave a SIMD), so every phase below is written to
+     * wait for memory as seldom as possible: all frequency loads are issued at once, LDS is read in batches of eight
+     * independent reads, and counters are bumped with return-less LDS atomics. */
     int n = 0, max_lcode = -1;
-    for (int g = 0; g < HROW / 8; g++) {
-        const uint4 fv = fq8[g];
-        const uint32_t fw[4] = {fv.x, fv.y, fv.z, fv.w};
+    long static_len = 0, xb_len = 0; /* block cost under the static code / extra bits of the length codes: known from the counts alone */
+    {
+        uint4 fv[HROW / 8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int sym = 8 * g + j;
-            if (sym >= LELEMS) continue;
-            const uint32_t f = (sym == 256) ? 1u : ((fw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-            if (f) { n++; HEAP(n) = (f << 16) | (uint32_t)sym; max_lcode = sym; }
+        for (int g = 0; g < HROW / 8; g++) fv[g] = fq8[g];
+#pragma unroll
+        for (int g = 0; g < HROW / 8; g++) {
+            const uint32_t fw[4] = {fv[g].x, fv[g].y, fv[g].z, fv[g].w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int sym = 8 * g + j;
+                if (sym >= LELEMS) continue;
+                const uint32_t f = (sym == 256) ? 1u : ((fw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                const int xb = sym >= 257 ? len_extra_bits(sym - 257) : 0;
+                static_len += (long)(f * (uint32_t)(static_llen(sym) + xb));
+                if (xb) xb_len += (long)(f * (uint32_t)xb);
+                if (f) { n++; HEAP(n) = (f << 16) | (uint32_t)sym; max_lcode = sym; }
+            }
         }
     }
+    HPHASE(0);
     /* a block always holds >= 1 symbol besides END_BLOCK, so n >= 2 (zlib's "force 2 codes" rule never fires) */
-    const int niter = merge_loop<HT>(tm.heap, tid, n, LELEMS);
+    uint32_t merged = 0; /* sum of the internal nodes' frequencies = sum of freq x code length, as long as no length is cut to 15 */
+    const int niter = merge_loop<HT>(tm.heap, tid, n, LELEMS, &merged);
+    HPHASE(1);
 
     int overflow = 0;
-    for (int i = 0; i < 16; i++) BLCOUNT(i) = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { BLCOUNT(i) = 0; NEXTCODE(i) = 0; }
     for (int it = niter - 1; it >= 0; it--) {
         const uint32_t w = HEAP(n - it);
         const int L = (int)(w >> 20); /* the root's record still has 0 there */
+        int bits = L + 1;
+        if (bits > 15) { bits = 15; overflow += 2; }
+#pragma unroll
         for (int side = 1; side >= 0; side--) { /* zlib walks m_i then n_i */
             const int child = (int)(side ? (w >> 10) & 0x3ffu : w & 0x3ffu);
-            int bits = L + 1;
-            if (bits > 15) { bits = 15; overflow++; }
-            if (child >= LELEMS) { HEAP(n - (child - LELEMS)) |= (uint32_t)bits << 20; continue; }
+            if (child >= LELEMS) { atomicOr(&HEAP(n - (child - LELEMS)), (uint32_t)bits << 20); continue; }
             LEAFLEN(child) = (uint8_t)bits;
-            BLCOUNT(bits) = (uint16_t)(BLCOUNT(bits) + 1);
+            atomicAdd(&BLCOUNT(bits), 1u);
         }
     }
+    HPHASE(2);
+    const bool repaired = overflow > 0;
     if (overflow > 0) {
         do {
             int bits = 14;
             while (BLCOUNT(bits) == 0) bits--;
-            BLCOUNT(bits) = (uint16_t)(BLCOUNT(bits) - 1);
-            BLCOUNT(bits + 1) = (uint16_t)(BLCOUNT(bits + 1) + 2);
-            BLCOUNT(15) = (uint16_t)(BLCOUNT(15) - 1);
+            BLCOUNT(bits) = BLCOUNT(bits) - 1;
+            BLCOUNT(bits + 1) = BLCOUNT(bits + 1) + 2;
+            BLCOUNT(15) = BLCOUNT(15) - 1;
             overflow -= 2;
         } while (overflow > 0);
         int h = 0;
         for (int bits = 15; bits != 0; bits--) {
-            int cnt = BLCOUNT(bits);
+            int cnt = (int)BLCOUNT(bits);
             while (cnt != 0) {
                 const int m = removed_node<HT>(tm.heap, tid, n, h);
                 h++;
@@ -226,42 +378,47 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
             }
         }
     }
-    /* canonical codes, and the block's cost under the dynamic and the static code (zlib keeps both sums up to
-     * date while it assigns and repairs lengths; they only depend on the final lengths) */
-    long opt_len = 0, static_len = 0;
+    HPHASE(3);
+    /* canonical codes, and the block's cost under the dynamic code (zlib keeps the sum up to date while it assigns and
+     * repairs lengths; it only depends on the final lengths) */
+    long opt_len = (long)merged + xb_len;
     uint32_t eob = 0;
     {
         uint32_t c = 0;
+#pragma unroll
         for (int bits = 1; bits <= 15; bits++) {
             c = (c + BLCOUNT(bits - 1)) << 1;
-            NEXTCODE(bits) = (uint16_t)c;
+            NEXTCODE(bits) = c;
         }
         for (int g = 0; g < HROW / 8; g++) {
-            const uint4 fv = fq8[g];
-            const uint32_t fw[4] = {fv.x, fv.y, fv.z, fv.w};
-            uint32_t e[8];
+            uint32_t l[8], cd[8], e[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int sym = 8 * g + j;
-                e[j] = 0;
-                if (sym >= LELEMS) continue;
-                const int l = LEAFLEN(sym);
-                if (l) {
-                    const uint32_t f = (sym == 256) ? 1u : ((fw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-                    const uint32_t cd = NEXTCODE(l);
-                    NEXTCODE(l) = (uint16_t)(cd + 1);
-                    e[j] = bit_reverse(cd, l) | ((uint32_t)l << 16);
-                    const int xb = sym >= 257 ? len_extra_bits(sym - 257) : 0;
-                    opt_len += (long)f * (l + xb);
-                    static_len += (long)f * (static_llen(sym) + xb);
-                    if (sym == 256) eob = e[j];
-                }
-            }
+            for (int j = 0; j < 8; j++) l[j] = (8 * g + j < LELEMS) ? LEAFLEN(8 * g + j) : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) cd[j] = l[j] ? atomicAdd(&NEXTCODE(l[j]), 1u) : 0u; /* in order: LDS atomics of one lane are */
+#pragma unroll
+            for (int j = 0; j < 8; j++) e[j] = l[j] ? (bit_reverse(cd[j], (int)l[j]) | (l[j] << 16)) : 0u;
+            if (g == 32) eob = e[0];
             reinterpret_cast<uint4 *>(code_out)[2 * g] = make_uint4(e[0], e[1], e[2], e[3]);
             reinterpret_cast<uint4 *>(code_out)[2 * g + 1] = make_uint4(e[4], e[5], e[6], e[7]);
         }
+        if (repaired) { /* lengths were cut to 15 and moved around: the cost is no longer the merge sum */
+            opt_len = xb_len;
+            for (int g = 0; g < HROW / 8; g++) {
+                const uint4 fv = fq8[g];
+                const uint32_t fw[4] = {fv.x, fv.y, fv.z, fv.w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int sym = 8 * g + j;
+                    if (sym >= LELEMS) continue;
+                    const uint32_t f = (sym == 256) ? 1u : ((fw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                    opt_len += (long)(f * (uint32_t)LEAFLEN(sym));
+                }
+            }
+        }
     }
 
+    HPHASE(4);
     /* ---------------- distance tree (only code 0 can occur: distance 1) ----------------
      * nmatch > 0: freq[0] = nmatch, node 1 forced with freq 1 -> both length 1, opt += nmatch,
      * static += 5 nmatch.  nmatch == 0: nodes 0 and 1 forced -> both length 1, net 0.  max_dcode = 1. */
@@ -270,33 +427,45 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
     static_len += 5L * (long)nmatch;
 
     /* ---------------- bit-length tree (its arrays live in the heap region from here on) ---------------- */
+#pragma unroll
     for (int i = 0; i < BLELEMS; i++) { BLFREQ(i) = 0; BLLEN(i) = 0; }
-    /* scan_tree over literal/length lengths [0, max_lcode], then over the distance lengths {1, 1} */
-    for (int pass = 0; pass < 2; pass++) {
-        const int maxc = pass == 0 ? max_lcode : 1;
-        int prevlen = -1, nextlen = pass == 0 ? LEAFLEN(0) : 1, count = 0, max_count = 7, min_count = 4;
-        if (nextlen == 0) { max_count = 138; min_count = 3; }
-        for (int i = 0; i <= maxc; i++) {
-            const int curlen = nextlen;
-            nextlen = (i + 1 <= maxc) ? (pass == 0 ? LEAFLEN(i + 1) : 1) : 0xffff;
-            if (++count < max_count && curlen == nextlen) continue;
-            else if (count < min_count) BLFREQ(curlen) += (uint32_t)count;
-            else if (curlen != 0) {
-                if (curlen != prevlen) BLFREQ(curlen) += 1u;
-                BLFREQ(16) += 1u;
-            } else if (count <= 10) BLFREQ(17) += 1u;
-            else BLFREQ(18) += 1u;
-            count = 0;
-            prevlen = curlen;
-            if (nextlen == 0) { max_count = 138; min_count = 3; }
-            else if (curlen == nextlen) { max_count = 6; min_count = 3; }
-            else { max_count = 7; min_count = 4; }
+    /* scan_tree over the literal/length lengths [0, max_lcode]; the distance lengths {1, 1} add two to length 1's count */
+    {
+        RunScan rs;
+        uint32_t c16 = 0, c17 = 0, c18 = 0;
+        uint32_t lookahead = LEAFLEN(0);
+        run_scan_init(rs, (int)lookahead);
+        for (int i0 = 0; i0 <= max_lcode; i0 += 8) {
+            uint32_t l[9];
+            l[0] = lookahead;
+#pragma unroll
+            for (int j = 1; j <= 8; j++) l[j] = (i0 + j < HSLOTS) ? LEAFLEN(i0 + j) : 0u;
+            lookahead = l[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j;
+                if (i > max_lcode) break;
+                const int curlen = (int)l[j], nextlen = i + 1 <= max_lcode ? (int)l[j + 1] : 0xffff;
+                const int act = run_scan_step(rs, curlen, nextlen);
+                if (act == RS_NONE) continue;
+                if (act == RS_LITERALS) atomicAdd(&BLFREQ(curlen), (uint32_t)rs.emit_count);
+                else if (act == RS_REP16 || act == RS_LIT_REP16) { if (act == RS_LIT_REP16) atomicAdd(&BLFREQ(curlen), 1u); c16++; }
+                else if (act == RS_REP17) c17++;
+                else c18++;
+            }
         }
+        BLFREQ(1) += 2u;
+        BLFREQ(16) = c16; BLFREQ(17) = c17; BLFREQ(18) = c18;
     }
+    HPHASE(5);
     int bn = 0, bl_max = -1;
-    for (int i = 0; i < BLELEMS; i++) {
-        const uint32_t f = BLFREQ(i);
-        if (f) { bn++; HEAP(bn) = (f << 16) | (uint32_t)i; bl_max = i; }
+    {
+        uint32_t f[BLELEMS];
+#pragma unroll
+        for (int i = 0; i < BLELEMS; i++) f[i] = BLFREQ(i);
+#pragma unroll
+        for (int i = 0; i < BLELEMS; i++)
+            if (f[i]) { bn++; HEAP(bn) = (f[i] << 16) | (uint32_t)i; bl_max = i; }
     }
     while (bn < 2) { /* zlib: force at least two codes of non zero frequency */
         const int node = bl_max < 2 ? ++bl_max : 0;
@@ -305,7 +474,9 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
         HEAP(bn) = (1u << 16) | (uint32_t)node;
         opt_len--;
     }
-    const int bniter = merge_loop<HT>(tm.heap, tid, bn, BLELEMS);
+    uint32_t blmerged = 0;
+    const int bniter = merge_loop<HT>(tm.heap, tid, bn, BLELEMS, &blmerged);
+#pragma unroll
     for (int i = 0; i < 16; i++) BLCOUNT(i) = 0;
     overflow = 0;
     for (int it = bniter - 1; it >= 0; it--) {
@@ -317,21 +488,21 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
             if (bits > 7) { bits = 7; overflow++; }
             if (child >= BLELEMS) { HEAP(bn - (child - BLELEMS)) |= (uint32_t)bits << 20; continue; }
             BLLEN(child) = (uint32_t)bits;
-            BLCOUNT(bits) = (uint16_t)(BLCOUNT(bits) + 1);
+            BLCOUNT(bits) = BLCOUNT(bits) + 1;
         }
     }
     if (overflow > 0) {
         do {
             int bits = 6;
             while (BLCOUNT(bits) == 0) bits--;
-            BLCOUNT(bits) = (uint16_t)(BLCOUNT(bits) - 1);
-            BLCOUNT(bits + 1) = (uint16_t)(BLCOUNT(bits + 1) + 2);
-            BLCOUNT(7) = (uint16_t)(BLCOUNT(7) - 1);
+            BLCOUNT(bits) = BLCOUNT(bits) - 1;
+            BLCOUNT(bits + 1) = BLCOUNT(bits + 1) + 2;
+            BLCOUNT(7) = BLCOUNT(7) - 1;
             overflow -= 2;
         } while (overflow > 0);
         int h = 0;
         for (int bits = 7; bits != 0; bits--) {
-            int cnt = BLCOUNT(bits);
+            int cnt = (int)BLCOUNT(bits);
             while (cnt != 0) {
                 const int m = removed_node<HT>(tm.heap, tid, bn, h);
                 h++;
@@ -343,19 +514,21 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
     }
     {
         uint32_t c = 0;
+#pragma unroll
         for (int bits = 1; bits <= 7; bits++) {
             c = (c + BLCOUNT(bits - 1)) << 1;
-            NEXTCODE(bits) = (uint16_t)c;
+            NEXTCODE(bits) = c;
         }
         for (int sym = 0; sym <= bl_max; sym++) {
             const int l = (int)BLLEN(sym);
-            if (!l) continue;
+            if (!l) { BLENT(sym) = 0; continue; }
             const uint32_t cd = NEXTCODE(l);
-            NEXTCODE(l) = (uint16_t)(cd + 1);
-            BLCODE(sym) = bit_reverse(cd, l);
+            NEXTCODE(l) = cd + 1;
+            BLENT(sym) = bit_reverse(cd, l) | ((uint32_t)l << 8);
             const int xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
             opt_len += (long)BLFREQ(sym) * (l + xb);
         }
+        for (int sym = bl_max + 1; sym < BLELEMS; sym++) BLENT(sym) = 0;
     }
     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     int max_blindex;
@@ -365,6 +538,7 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
     }
     opt_len += 3 * (max_blindex + 1) + 5 + 5 + 4;
 
+    HPHASE(6);
     /* ---------------- dynamic header bit string (send_all_trees) ---------------- */
     HdrWriter hw;
     hw.dst = blkhdr + ((size_t)s * MAXBLK + b) * HDRWORDS;
@@ -376,33 +550,44 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
         const int o = order[r];
         hw_put(hw, o <= bl_max ? BLLEN(o) : 0u, 3);
     }
-    for (int pass = 0; pass < 2; pass++) {
-        const int maxc = pass == 0 ? max_lcode : 1;
-        int prevlen = -1, nextlen = pass == 0 ? LEAFLEN(0) : 1, count = 0, max_count = 7, min_count = 4;
-        if (nextlen == 0) { max_count = 138; min_count = 3; }
-        for (int i = 0; i <= maxc; i++) {
-            const int curlen = nextlen;
-            nextlen = (i + 1 <= maxc) ? (pass == 0 ? LEAFLEN(i + 1) : 1) : 0xffff;
-            if (++count < max_count && curlen == nextlen) continue;
-            else if (count < min_count) {
-                do { hw_put(hw, BLCODE(curlen), BLLEN(curlen)); } while (--count != 0);
-            } else if (curlen != 0) {
-                if (curlen != prevlen) { hw_put(hw, BLCODE(curlen), BLLEN(curlen)); count--; }
-                hw_put(hw, BLCODE(16), BLLEN(16));
-                hw_put(hw, (uint32_t)(count - 3), 2);
-            } else if (count <= 10) {
-                hw_put(hw, BLCODE(17), BLLEN(17));
-                hw_put(hw, (uint32_t)(count - 3), 3);
-            } else {
-                hw_put(hw, BLCODE(18), BLLEN(18));
-                hw_put(hw, (uint32_t)(count - 11), 7);
+    {
+        const uint32_t e16 = BLENT(16), e17 = BLENT(17), e18 = BLENT(18), e1 = BLENT(1);
+        RunScan rs;
+        uint32_t lookahead = LEAFLEN(0);
+        run_scan_init(rs, (int)lookahead);
+        for (int i0 = 0; i0 <= max_lcode; i0 += 8) {
+            uint32_t l[9], ent[8];
+            l[0] = lookahead;
+#pragma unroll
+            for (int j = 1; j <= 8; j++) l[j] = (i0 + j < HSLOTS) ? LEAFLEN(i0 + j) : 0u;
+            lookahead = l[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) ent[j] = BLENT(l[j]); /* eight independent reads: one wait */
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j;
+                if (i > max_lcode) break;
+                const int curlen = (int)l[j], nextlen = i + 1 <= max_lcode ? (int)l[j + 1] : 0xffff;
+                const int act = run_scan_step(rs, curlen, nextlen);
+                if (act == RS_NONE) continue;
+                const uint32_t cc = ent[j] & 0xffu;
+                const int cl = (int)(ent[j] >> 8);
+                if (act == RS_LITERALS) {
+                    int k = rs.emit_count; /* 1..3 */
+                    do { hw_put(hw, cc, cl); } while (--k != 0);
+                } else if (act == RS_REP16 || act == RS_LIT_REP16) {
+                    if (act == RS_LIT_REP16) hw_put(hw, cc, cl);
+                    hw_put(hw, (e16 & 0xffu) | ((uint32_t)(rs.emit_count - 3) << (e16 >> 8)), (int)(e16 >> 8) + 2);
+                } else if (act == RS_REP17) {
+                    hw_put(hw, (e17 & 0xffu) | ((uint32_t)(rs.emit_count - 3) << (e17 >> 8)), (int)(e17 >> 8) + 3);
+                } else {
+                    hw_put(hw, (e18 & 0xffu) | ((uint32_t)(rs.emit_count - 11) << (e18 >> 8)), (int)(e18 >> 8) + 7);
+                }
             }
-            count = 0;
-            prevlen = curlen;
-            if (nextlen == 0) { max_count = 138; min_count = 3; }
-            else if (curlen == nextlen) { max_count = 6; min_count = 3; }
-            else { max_count = 7; min_count = 4; }
         }
+        /* the distance tree's two lengths {1, 1}: a run of two, sent as two literals */
+        hw_put(hw, e1 & 0xffu, (int)(e1 >> 8));
+        hw_put(hw, e1 & 0xffu, (int)(e1 >> 8));
     }
     hw_finish(hw);
 
@@ -412,6 +597,9 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
     m.hdr_bits = hw.total;
     m.eob = eob;
     meta[(size_t)s * MAXBLK + b] = m;
+    HPHASE(7);
+    if (dbg) atomicAdd(&dbg[32], 1ull);
+#undef HPHASE
 }
 
 } /* namespace mrcz */

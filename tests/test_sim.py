@@ -40,6 +40,18 @@ def test_run_lengths_around_258(simlib, oracle):
     _check(simlib, oracle, np.full(70000, 0x41200000, np.uint32), 0)
 
 
+def test_skewed_alphabets_force_length_overflow(simlib, oracle):
+    # Fibonacci byte frequencies push Huffman depths past 15 bits (overflow repair, and the cost recomputed from lengths)
+    fib = [1, 1]
+    while sum(fib) < 30000:
+        fib.append(fib[-1] + fib[-2])
+    rng = np.random.default_rng(3)
+    p0 = np.concatenate([np.full(f, i, np.uint32) for i, f in enumerate(fib)])
+    rng.shuffle(p0)
+    w = p0 | (rng.integers(0, 4, len(p0), dtype=np.uint64).astype(np.uint32) << 8)
+    _check(simlib, oracle, np.tile(w, 2), 0)
+
+
 def test_kat_a(simlib, oracle):
     w = util.kat_words(300000)
     for b in (0, 23):

@@ -55,6 +55,13 @@ if which == "compress":
     for lanes, stagger, ht in [(2, 0, 48), (2, 1, 48), (3, 1, 48), (4, 1, 48), (2, 1, 16), (3, 1, 16), (4, 1, 16), (4, 1, 32), (4, 0, 16), (1, 0, 48)]:
         res.append(run({"MRCZ_LANES": lanes, "MRCZ_STAGGER": stagger, "MRCZ_HT": ht}))
         print(json.dumps(res[-1]), flush=True)
+elif which == "split":
+    for split, stagger in [(50, 1), (25, 1), (35, 1), (65, 1), (75, 1), (85, 1), (25, 0), (75, 0)]:
+        res.append(run({"MRCZ_LANES": 2, "MRCZ_STAGGER": stagger, "MRCZ_SPLIT": split}))
+        print(json.dumps(res[-1]), flush=True)
+    for lanes in (3, 4):
+        res.append(run({"MRCZ_LANES": lanes, "MRCZ_STAGGER": 1}))
+        print(json.dumps(res[-1]), flush=True)
 elif which == "decompress":
     for grid in (512, 768, 1024, 1536, 3072):
         res.append(run({"MRCZ_BLK_GRID": grid}))
