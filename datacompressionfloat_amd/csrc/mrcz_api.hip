@@ -34,6 +34,7 @@ struct mrcz_ctx {
     hipStream_t lane_stream[MAX_LANES]; /* ... the lanes of a compress batch (see mrcz_compress_chunks); [0] = stream */
     hipEvent_t ev_start, ev_cont, ev_done[MAX_LANES];
     hipEvent_t ev_stream[MAX_LANES]; /* lane l's summary + histogram passes are done */
+    uint32_t use_hint;             /* block decoder: size the pieces of a window by where the block probably ends (MRCZ_HINT=0: off) */
     uint32_t split_pct;            /* two lanes: share of a batch's chunks (per cent) the first lane takes; MRCZ_SPLIT overrides it */
     int stagger;                   /* lanes start one after the other (each once the previous one's streaming passes are done), so that
                                     * their Huffman kernels -- one tree's latency long, nearly idle machine -- run under the other lanes'
@@ -142,7 +143,13 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->lanes = 2;
     if (const char *ev = getenv("MRCZ_LANES")) { const int v = atoi(ev); if (v >= 1 && v <= MAX_LANES) ctx->lanes = (uint32_t)v; }
     if (max_batch_chunks < 8u) ctx->lanes = 1; /* batches under 8 chunks run as one lane anyway */
-    for (uint32_t l = 1; l < ctx->lanes && e == hipSuccess; l++) e = hipStreamCreate(&ctx->lane_stream[l]);
+    {   /* MRCZ_PRIO (experiments): bit l set = lane l's stream is created with the highest priority */
+        int prio_mask = 0, plo = 0, phi = 0;
+        if (const char *ev = getenv("MRCZ_PRIO")) prio_mask = atoi(ev);
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+        for (uint32_t l = 1; l < ctx->lanes && e == hipSuccess; l++)
+            e = ((prio_mask >> l) & 1) ? hipStreamCreateWithPriority(&ctx->lane_stream[l], hipStreamDefault, phi) : hipStreamCreate(&ctx->lane_stream[l]);
+    }
     {   /* the block decoder runs as a fixed grid of three workgroups per CU (its LDS footprint admits exactly three) */
         hipDeviceProp_t prop;
         ctx->blk_grid = 768;
@@ -162,6 +169,8 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->stagger = 1;
     ctx->huff_ht = 48;
     ctx->split_pct = 50;
+    ctx->use_hint = 1;
+    if (const char *ev = getenv("MRCZ_HINT")) ctx->use_hint = atoi(ev) ? 1u : 0u;
     if (const char *ev = getenv("MRCZ_SPLIT")) { const int v = atoi(ev); if (v >= 5 && v <= 95) ctx->split_pct = (uint32_t)v; }
     if (const char *ev = getenv("MRCZ_STAGGER")) ctx->stagger = atoi(ev) ? 1 : 0;
     if (const char *ev = getenv("MRCZ_HT")) { const int v = atoi(ev); if (v == 16 || v == 32 || v == 48) ctx->huff_ht = v; }
@@ -346,7 +355,7 @@ static int compress_lane(mrcz_ctx *ctx, hipStream_t lstream, int phase, int slot
         LAUNCH("k_histogram", k_histogram, dim3(SPS, nb, 4), dim3(64), planes, bfl, tinfo, pairhist, blkstart, slideq);
         LAUNCH("k_block_reduce", k_block_reduce, dim3(MAXBLK, ns), dim3(64), tinfo, sinfo, pairhist, blkfreq);
         LAUNCH("k_block_index", k_block_index, dim3(1), dim3(256), sinfo, ns, blkbase);
-        if (ctx->stagger) HIPCHK(hipEventRecord(ctx->ev_stream[slot], lstream), "event"); /* this lane's streaming passes are done: the next lane may start */
+        HIPCHK(hipEventRecord(ctx->ev_stream[slot], lstream), "event"); /* this lane's streaming passes are done: the next lane may start */
         unsigned long long *hdbg = ctx->phase_profile == 3 ? ctx->dbgphase : (unsigned long long *)NULL; /* developer tool */
         if (ctx->huff_ht == 16) LAUNCH("k_huffman", k_huffman<16>, dim3((ns * MAXBLK + 15) / 16), dim3(16), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
         else if (ctx->huff_ht == 32) LAUNCH("k_huffman", k_huffman<32>, dim3((ns * MAXBLK + 31) / 32), dim3(32), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
@@ -433,6 +442,13 @@ static int compress_enqueue(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats,
                 hipStream_t st = ctx->lane_stream[l];
                 if (phase == 1) { /* layout: strictly in lane (= file) order */
                     if (cont_pending) HIPCHK(hipStreamWaitEvent(st, ctx->ev_cont, 0), "wait");
+                }
+                if (phase == 2 && l + 1u < nlanes) {
+                    /* The emit kernel fills every CU for as long as it runs, and small kernels queued behind it on another
+                     * stream wait for hundreds of microseconds (measured: k_block_index, one workgroup, 333 us).  The next
+                     * lane's Huffman kernel is what the end of the batch hangs on, so this lane's emit does not start before
+                     * that lane's streaming passes are through and its Huffman kernel is next in line. */
+                    HIPCHK(hipStreamWaitEvent(st, ctx->ev_stream[l + 1u], 0), "wait");
                 }
                 if (phase == 0 && ctx->stagger && nlanes > 1) {
                     /* start after the streaming passes of the lane submitted just before this one (the last lane of the
@@ -544,7 +560,7 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
             /* fixed grid: the workgroups pull candidate numbers from ctx->njobs[0] until it passes candbase[ns] (no read-back) */
             LAUNCH("k_blk_count", k_blk_count, dim3(ctx->blk_grid), dim3(PT), rec, len, ctx->dstreams, ns, ctx->candbase,
                      ctx->cands, ctx->scratch + 16, ctx->njobs + 2, (uint32_t)(ctx->scratch_bytes >> 4), ctx->hdrs, ctx->calltag, ctx->njobs,
-                     ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL);
+                     ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL, ctx->use_hint);
         }
         LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->segs, ctx->nseg, ctx->segidx,
                ctx->fallback, ctx->phase_profile == 1 ? 1u : 0u);

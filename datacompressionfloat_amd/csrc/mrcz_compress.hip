@@ -513,59 +513,95 @@ __global__ __launch_bounds__(64) void k_block_reduce(const TileInfo *__restrict_
 /* ======================================================================================
  * stream layout: block types, bit offsets, RAW decision  (one workgroup of 64 per stream)
  * ==================================================================================== */
+/* Where a block starts depends on everything before it, but only through one number: bit -> bit + size for a coded
+ * block, bit -> (bit + 10 rounded down to a byte) + 32 + 8 len for a stored one (type bits, pad, LEN, NLEN, data).
+ * Maps of the form  x -> x + a2  and  x -> ((x + a1) & ~7) + a2  are closed under composition, so the blocks' start
+ * bits are a prefix "sum" of such maps: each lane composes its few consecutive blocks, one wave scan, done. */
+struct BitMap { uint32_t al, a1, a2; }; /* al = 0: x + a2;  al = 1: ((x + a1) & ~7) + a2 */
+__device__ __forceinline__ BitMap bitmap_then(const BitMap f, const BitMap g) /* g after f */
+{
+    BitMap r;
+    if (!g.al) { r.al = f.al; r.a1 = f.a1; r.a2 = f.a2 + g.a2; }
+    else if (!f.al) { r.al = 1; r.a1 = f.a2 + g.a1; r.a2 = g.a2; }
+    else { r.al = 1; r.a1 = f.a1; r.a2 = ((f.a2 + g.a1) & ~7u) + g.a2; } /* f's value is a multiple of 8 plus f.a2 */
+    return r;
+}
+__device__ __forceinline__ uint32_t bitmap_apply(const BitMap f, uint32_t x) { return f.al ? ((x + f.a1) & ~7u) + f.a2 : x + f.a2; }
+
 __global__ __launch_bounds__(64) void k_stream_layout(StreamInfo *__restrict__ sinfo, const BlkMeta *__restrict__ meta,
                                                       const uint32_t *__restrict__ blkstart,
                                                       const uint32_t *__restrict__ slideq, BlkLay *__restrict__ lay)
 {
-    __shared__ uint32_t s_opt[MAXBLK], s_stat[MAXBLK], s_hdr[MAXBLK], s_start[MAXBLK + 1], s_q[MAXSLIDE];
+    __shared__ uint32_t s_q[MAXSLIDE];
     const uint32_t s = blockIdx.x;
     StreamInfo si = sinfo[s];
     const int lane = lane_id();
     const uint32_t nslide = slide_count(si.n);
-    for (uint32_t i = lane; i < si.nblk; i += 64) {
-        const BlkMeta m = meta[(size_t)s * MAXBLK + i];
-        s_opt[i] = m.opt_len; s_stat[i] = m.static_len; s_hdr[i] = m.hdr_bits;
-    }
-    for (uint32_t i = lane; i <= si.nblk; i += 64) s_start[i] = blkstart[(size_t)s * (MAXBLK + 1) + i];
     for (uint32_t i = lane; i <= nslide; i += 64) s_q[i] = i ? slideq[(size_t)s * MAXSLIDE + i] : 0u;
-    __syncthreads();
-    if (lane != 0) return;
-    uint32_t bit = 0;
-    uint32_t k = 1; /* next slide to account for */
-    for (uint32_t b = 0; b < si.nblk; b++) {
-        const uint32_t start = s_start[b], end = s_start[b + 1];
+    __builtin_amdgcn_wave_barrier();
+    constexpr int R = (MAXBLK + 63) / 64; /* consecutive blocks per lane */
+    const uint32_t per = (si.nblk + 63u) / 64u; /* <= R */
+    const uint32_t b0 = (uint32_t)lane * per;
+    uint32_t btype[R], size_or_len[R], hdr[R];
+    BitMap mine; mine.al = 0; mine.a1 = 0; mine.a2 = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t b = b0 + (uint32_t)r;
+        btype[r] = 3; size_or_len[r] = 0; hdr[r] = 0;
+        if ((uint32_t)r >= per || b >= si.nblk) continue;
+        const BlkMeta m = meta[(size_t)s * MAXBLK + b];
+        const uint32_t start = blkstart[(size_t)s * (MAXBLK + 1) + b], end = blkstart[(size_t)s * (MAXBLK + 1) + b + 1];
         const bool full = (b + 1 < si.nblk) || (si.nsym == si.nblk * BLK_SYMS);
-        /* slides that happened before this block was flushed: in-loop flush sees q_k < end,
-         * the final partial block is flushed after the loop and sees all of them */
-        while (k <= nslide && (full ? s_q[k] < end : true)) k++;
-        const uint32_t base = 32768u * (k - 1u);
-        const bool stored_ok = start >= base;
-        const uint32_t opt_len = s_opt[b], static_len = s_stat[b];
-        uint32_t opt_lenb = (opt_len + 3u + 7u) >> 3;
-        const uint32_t static_lenb = (static_len + 3u + 7u) >> 3;
+        /* slides that happened before this block was flushed: an in-loop flush sees the slides with q_k < end (q is
+         * increasing), the final partial block is flushed after the loop and sees all of them */
+        uint32_t k = nslide + 1u;
+        if (full) {
+            uint32_t lo = 1, hi = nslide + 1u; /* first k with q_k >= end */
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_q[mid] < end) lo = mid + 1u; else hi = mid; }
+            k = lo;
+        }
+        const bool stored_ok = start >= 32768u * (k - 1u);
+        uint32_t opt_lenb = (m.opt_len + 3u + 7u) >> 3;
+        const uint32_t static_lenb = (m.static_len + 3u + 7u) >> 3;
         if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
         const uint32_t stored_len = end - start;
+        BitMap f;
+        if (stored_len + 4u <= opt_lenb && stored_ok) { btype[r] = 0; size_or_len[r] = stored_len; f.al = 1; f.a1 = 3u + 7u; f.a2 = 32u + 8u * stored_len; }
+        else if (static_lenb == opt_lenb) { btype[r] = 1; size_or_len[r] = m.static_len; f.al = 0; f.a1 = 0; f.a2 = 3u + m.static_len; }
+        else { btype[r] = 2; size_or_len[r] = m.opt_len; hdr[r] = m.hdr_bits; f.al = 0; f.a1 = 0; f.a2 = 3u + m.opt_len; }
+        mine = bitmap_then(mine, f);
+    }
+    /* inclusive scan of the lanes' maps, then the start bit of my first block = (maps of the lanes before me)(0) */
+    BitMap inc = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        BitMap o;
+        o.al = (uint32_t)__shfl_up((int)inc.al, d); o.a1 = (uint32_t)__shfl_up((int)inc.a1, d); o.a2 = (uint32_t)__shfl_up((int)inc.a2, d);
+        if (lane >= d) inc = bitmap_then(o, inc);
+    }
+    BitMap before;
+    before.al = (uint32_t)__shfl_up((int)inc.al, 1); before.a1 = (uint32_t)__shfl_up((int)inc.a1, 1); before.a2 = (uint32_t)__shfl_up((int)inc.a2, 1);
+    uint32_t bit = lane ? bitmap_apply(before, 0u) : 0u;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (btype[r] == 3u) continue;
         BlkLay L;
         L.bitpos = bit;
-        if (stored_len + 4u <= opt_lenb && stored_ok) {
-            L.btype = 0;
+        L.btype = btype[r];
+        if (btype[r] == 0u) {
             const uint32_t db = ((bit + 3u + 7u) & ~7u) + 32u; /* type bits, pad, LEN, NLEN */
             L.databit = db;
-            bit = db + 8u * stored_len;
-        } else if (static_lenb == opt_lenb) {
-            L.btype = 1;
-            L.databit = bit + 3u;
-            bit += 3u + static_len;
+            bit = db + 8u * size_or_len[r];
         } else {
-            L.btype = 2;
-            L.databit = bit + 3u + s_hdr[b];
-            bit += 3u + opt_len;
+            L.databit = bit + 3u + hdr[r];
+            bit += 3u + size_or_len[r];
         }
         L.endbit = bit;
-        lay[(size_t)s * MAXBLK + b] = L;
+        lay[(size_t)s * MAXBLK + b0 + (uint32_t)r] = L;
     }
-    si.zbits = bit;
-    const uint32_t zlen = ((bit + 3u + 7u) >> 3) + 4u; /* 000, pad, 00 00 FF FF */
+    const uint32_t total = (uint32_t)__shfl((int)bitmap_apply(inc, 0u), 63);
+    if (lane != 0) return;
+    si.zbits = total;
+    const uint32_t zlen = ((total + 3u + 7u) >> 3) + 4u; /* 000, pad, 00 00 FF FF */
     si.zlen = zlen;
     /* zip.c:170-177: zlib's output is capped at avail_out = chk, then COMPRESSED iff inlen > len + 4 */
     const uint32_t len = zlen > CHK ? CHK : zlen;
@@ -617,33 +653,54 @@ __global__ __launch_bounds__(64) void k_pair_offsets(const StreamInfo *__restric
                                                      const TileInfo *__restrict__ tinfo, const uint32_t *__restrict__ pairbits,
                                                      uint32_t *__restrict__ pairoff)
 {
-    __shared__ uint32_t s_pb[MAXPAIR];
-    __shared__ uint32_t s_pseg[SPS + 1];
-    __shared__ uint32_t s_db[MAXBLK];
+    /* Pair (g, b) = the part of block b that lies in segment g, pair id g + b; the pairs of a stream in id order walk
+     * through the segments and, inside a segment, through the blocks it touches.  Where a pair's bits start: at the
+     * block's data bit if it is the block's first pair, else behind the pair before it.  That is a segmented prefix sum
+     * over the pair ids: val[i] = data bit of the block (head) or the bits of pair i - 1. */
+    __shared__ uint32_t s_val[MAXPAIR];
+    __shared__ uint8_t s_head[MAXPAIR];
     const uint32_t s = blockIdx.x;
     const StreamInfo si = sinfo[s];
     const int lane = lane_id();
     const TileInfo *ti = tinfo + (size_t)s * TPS;
-    for (uint32_t g = lane; g < si.nseg; g += 64) s_pseg[g] = ti[g * TILES_PER_SEG].P;
-    if (lane == 0) s_pseg[si.nseg] = si.nsym;
-    for (uint32_t i = lane; i < si.nseg + si.nblk + 1 && i < (uint32_t)MAXPAIR; i += 64) s_pb[i] = pairbits[(size_t)s * MAXPAIR + i];
-    for (uint32_t b = lane; b < si.nblk; b += 64) s_db[b] = lay[(size_t)s * MAXBLK + b].databit;
-    __syncthreads();
-    if (lane != 0) return;
-    uint32_t *po = pairoff + (size_t)s * MAXPAIR;
-    uint32_t g = 0, b = 0;
-    uint32_t off = si.nblk ? s_db[0] : 0u;
-    for (;;) {
-        po[g + b] = off;
-        const uint32_t bend = s_pseg[g + 1] / BLK_SYMS; /* last block this segment touches */
-        if (b < bend) {
-            b++;
-            off = b < si.nblk ? s_db[b] : 0u;
-        } else {
-            off += s_pb[g + b];
-            g++;
-            if (g >= si.nseg) break;
+    const uint32_t npair = si.nseg ? si.nseg + si.nsym / BLK_SYMS : 0u; /* the last segment ends in block nsym / BLK_SYMS */
+    for (uint32_t g = lane; g < si.nseg; g += 64) {
+        const uint32_t bs = ti[g * TILES_PER_SEG].P / BLK_SYMS;
+        const uint32_t be = ((g + 1 < si.nseg) ? ti[(g + 1) * TILES_PER_SEG].P : si.nsym) / BLK_SYMS;
+        for (uint32_t b = bs; b <= be; b++) {
+            const uint32_t i = g + b;
+            if (i >= (uint32_t)MAXPAIR) break;
+            const bool head = b > bs || g == 0u; /* the block's first pair */
+            s_head[i] = head ? 1 : 0;
+            s_val[i] = head ? (b < si.nblk ? lay[(size_t)s * MAXBLK + b].databit : 0u) : pairbits[(size_t)s * MAXPAIR + i - 1u];
         }
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int R = (MAXPAIR + 63) / 64;
+    const uint32_t per = (npair + 63u) / 64u;
+    const uint32_t i0 = (uint32_t)lane * per;
+    /* lane-local segmented sums, then a wave scan of (has a head, sum since the last head) */
+    uint32_t sum = 0, flag = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = i0 + (uint32_t)r;
+        if ((uint32_t)r >= per || i >= npair) continue;
+        if (s_head[i]) { sum = s_val[i]; flag = 1; } else sum += s_val[i];
+    }
+    uint32_t isum = sum, iflag = flag;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t os = (uint32_t)__shfl_up((int)isum, d), of = (uint32_t)__shfl_up((int)iflag, d);
+        if (lane >= d) { if (!iflag) isum += os; iflag |= of; }
+    }
+    uint32_t run = (uint32_t)__shfl_up((int)isum, 1);
+    if (lane == 0) run = 0;
+    uint32_t *po = pairoff + (size_t)s * MAXPAIR;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t i = i0 + (uint32_t)r;
+        if ((uint32_t)r >= per || i >= npair) continue;
+        run = s_head[i] ? s_val[i] : run + s_val[i];
+        po[i] = run;
     }
 }
 

@@ -41,32 +41,33 @@ template <int HT> struct TreeMem {
 #define LEAFLEN(i) tm.leaflen[(i) * HT + tid]
 #define BLCOUNT(i) tm.blcount[(i) * HT + tid]
 #define NEXTCODE(i) tm.nextcode[(i) * HT + tid]
-/* bit-length tree, inside the heap region: heap + merge records in slots 1..19 */
-#define BLFREQ(i) HEAP(32 + (i))
-#define BLLEN(i) HEAP(64 + (i))
-#define BLENT(i) HEAP(96 + (i))   /* bit-length code of symbol i | its length << 8: one read per header symbol */
+/* bit-length tree, inside the heap region: heap + merge records in slots 1..19, KEY_INF up to slot 39 */
+#define BLFREQ(i) HEAP(48 + (i))
+#define BLLEN(i) HEAP(80 + (i))
+#define BLENT(i) HEAP(112 + (i))  /* bit-length code of symbol i | its length << 8: one read per header symbol */
 
 /* zlib's pqdownheap with the value to place passed in a register.  The kernel's time is ONE tree's dependent
  * instruction chain (a wave holds 48 trees and nothing else runs on its SIMD), so the loop is kept to the bare
- * minimum: nodes are addressed by their element offset o = node * HT (child = 2 o, no multiplies), both children are
- * always read (the offset of a missing right child is clamped) so the two LDS reads are independent, and
- * smaller(a, b) = (a >> 10) <= (b >> 10) is evaluated as a <= (b | 1023). */
-template <int HT> __device__ __forceinline__ void sift_down(uint32_t *heap, int tid, int heap_len, int k, uint32_t v)
+ * minimum: nodes are addressed by their element offset o = node * HT (child = 2 o, no multiplies), both children
+ * come with one ds_read2, and smaller(a, b) = (a >> 10) <= (b >> 10) is evaluated as a <= (b | 1023).
+ * There is no "does this child exist" test: every slot behind the end of the heap holds a value above all keys
+ * (KEY_INF, or a merge record, which carries REC_TAG), so a missing child is never preferred to a real one and the
+ * walk stops at a node whose children are both missing.  Nodes >= HSLOTS / 2 have no slots for children. */
+constexpr uint32_t KEY_INF = 0xffffffffu;
+constexpr uint32_t REC_TAG = 0xc0000000u; /* keys are < 0x80010000: freq <= 32768 */
+template <int HT> __device__ __forceinline__ void sift_lds(uint32_t *hp /* heap + tid */, int o /* node * HT */, uint32_t v)
 {
-    uint32_t *hp = heap + tid;
-    const int lim = heap_len * HT;
-    int a = k * HT, aj = a << 1;
-    while (aj <= lim) {
-        const int aj1 = aj < lim ? aj + HT : aj;
-        uint32_t cj = hp[aj];
-        const uint32_t cj1 = hp[aj1];
-        if (aj1 != aj && cj1 <= (cj | 1023u)) { aj = aj1; cj = cj1; }
+    int aj = o << 1;
+    while (aj <= (HSLOTS - 2) * HT) {
+        const uint32_t c0 = hp[aj], c1 = hp[aj + HT];
+        const bool right = c1 <= (c0 | 1023u);
+        const uint32_t cj = right ? c1 : c0;
         if (v <= (cj | 1023u)) break;
-        hp[a] = cj;
-        a = aj;
-        aj <<= 1;
+        hp[o] = cj;
+        o = right ? aj + HT : aj;
+        aj = o << 1;
     }
-    hp[a] = v;
+    hp[o] = v;
 }
 
 /* The merge loop's two sifts per merge start at the root, and a sift costs one LDS round trip plus ~25 instructions per
@@ -74,7 +75,6 @@ template <int HT> __device__ __forceinline__ void sift_down(uint32_t *heap, int 
  * 1..15) live in registers during the merge loop: a level there is a handful of selects.  Register slots beyond the
  * end of the heap hold KEY_INF, a key no node has (freq <= 32768), which makes the "has a child" tests of these levels
  * fall out of the comparisons themselves.  LDS slots 1..15 are dead meanwhile and take merge records as before. */
-constexpr uint32_t KEY_INF = 0xffffffffu;
 struct HeapTop { uint32_t r[16]; }; /* r[1..15]; every index below is a compile-time constant after unrolling */
 
 #define TOP_WRITE(top, lo, a, x)                                                       \
@@ -82,7 +82,7 @@ struct HeapTop { uint32_t r[16]; }; /* r[1..15]; every index below is a compile-
         _Pragma("unroll") for (int i_ = (lo); i_ < 2 * (lo); i_++) (top).r[i_] = ((a) == i_) ? (x) : (top).r[i_]; \
     } while (0)
 
-template <int HT> __device__ __forceinline__ void sift_root(HeapTop &t, uint32_t *hp /* heap + tid */, int heap_len, uint32_t v)
+template <int HT> __device__ __forceinline__ void sift_root(HeapTop &t, uint32_t *hp /* heap + tid */, uint32_t v)
 {
     /* level 0: children 2, 3 */
     uint32_t cj = t.r[2];
@@ -115,41 +115,31 @@ template <int HT> __device__ __forceinline__ void sift_root(HeapTop &t, uint32_t
         if (stop) return;
         a = 2 * a + (right ? 1 : 0);
     }
-    /* level 3: node a in 8..15 (a register), children 16..31 in LDS; deeper levels as in sift_down */
-    const int lim = heap_len * HT;
-    int aj = 2 * a * HT;
-    if (aj > lim) { TOP_WRITE(t, 8, a, v); return; }
+    /* level 3: node a in 8..15 (a register), children 16..31 in LDS; deeper levels as in sift_lds */
+    int o = 2 * a * HT;
     {
-        const int aj1 = aj < lim ? aj + HT : aj;
-        cj = hp[aj];
-        const uint32_t cj1 = hp[aj1];
-        if (aj1 != aj && cj1 <= (cj | 1023u)) { aj = aj1; cj = cj1; }
+        const uint32_t c0 = hp[o], c1 = hp[o + HT];
+        const bool right = c1 <= (c0 | 1023u);
+        cj = right ? c1 : c0;
         const bool stop = v <= (cj | 1023u);
         const uint32_t put = stop ? v : cj;
         TOP_WRITE(t, 8, a, put);
         if (stop) return;
+        o = right ? o + HT : o;
     }
-    int o = aj;
-    aj <<= 1;
-    while (aj <= lim) {
-        const int aj1 = aj < lim ? aj + HT : aj;
-        cj = hp[aj];
-        const uint32_t cj1 = hp[aj1];
-        if (aj1 != aj && cj1 <= (cj | 1023u)) { aj = aj1; cj = cj1; }
-        if (v <= (cj | 1023u)) break;
-        hp[o] = cj;
-        o = aj;
-        aj <<= 1;
-    }
-    hp[o] = v;
+    sift_lds<HT>(hp, o, v);
 }
 
 /* heap holds n0 leaf keys (1-based).  Runs zlib's merge loop; returns the number of merges.  Merge i removes
  * n_i then m_i and creates internal node elems + i; its record lands in slot n0 - i. */
 template <int HT> __device__ __forceinline__ int merge_loop(uint32_t *heap, int tid, int n0, int elems, uint32_t *merged)
 {
-    for (int k = n0 / 2; k >= 1; k--) sift_down<HT>(heap, tid, n0, k, heap[k * HT + tid]);
     uint32_t *hp = heap + tid;
+    {   /* slots a walk can look at behind the end of the heap */
+        const int last = 2 * n0 + 1 < HSLOTS ? 2 * n0 + 1 : HSLOTS - 1;
+        for (int k = n0 + 1; k <= last; k++) hp[k * HT] = KEY_INF;
+    }
+    for (int k = n0 / 2; k >= 1; k--) sift_lds<HT>(hp, k * HT, hp[k * HT]);
     HeapTop t;
 #pragma unroll
     for (int i = 1; i < 16; i++) t.r[i] = i <= n0 ? hp[i * HT] : KEY_INF;
@@ -158,8 +148,10 @@ template <int HT> __device__ __forceinline__ int merge_loop(uint32_t *heap, int 
     do {
         const uint32_t nkey = t.r[1];
         uint32_t lastv;
-        if (heap_len >= 16) lastv = hp[heap_len * HT];
-        else { /* the last node is one of the registers, and its slot leaves the heap */
+        if (heap_len >= 16) {
+            lastv = hp[heap_len * HT];
+            hp[heap_len * HT] = REC_TAG | (nkey & 0x3ffu); /* the slot leaves the heap; the record is completed below */
+        } else { /* the last node is one of the registers, and its slot leaves the heap */
             lastv = 0;
 #pragma unroll
             for (int i = 1; i < 16; i++) {
@@ -168,14 +160,14 @@ template <int HT> __device__ __forceinline__ int merge_loop(uint32_t *heap, int 
             }
         }
         heap_len--;
-        sift_root<HT>(t, hp, heap_len, lastv);
+        sift_root<HT>(t, hp, lastv);
         const uint32_t mkey = t.r[1];
-        hp[(heap_len + 1) * HT] = (nkey & 0x3ffu) | ((mkey & 0x3ffu) << 10);
+        hp[(heap_len + 1) * HT] = REC_TAG | (nkey & 0x3ffu) | ((mkey & 0x3ffu) << 10);
         const uint32_t f = (nkey >> 16) + (mkey >> 16);
         msum += f;
         const uint32_t dn = (nkey >> 10) & 63u, dm = (mkey >> 10) & 63u;
         const uint32_t d = (dn >= dm ? dn : dm) + 1u;
-        sift_root<HT>(t, hp, heap_len, (f << 16) | (d << 10) | (uint32_t)(elems + it));
+        sift_root<HT>(t, hp, (f << 16) | (d << 10) | (uint32_t)(elems + it));
         it++;
     } while (heap_len >= 2);
     *merged = msum;
@@ -215,34 +207,39 @@ __device__ __forceinline__ void hw_finish(HdrWriter &h)
 __device__ __forceinline__ uint32_t bit_reverse(uint32_t code, int len) { return __brev(code) >> (32 - len); }
 
 /* zlib's scan_tree / send_tree walk over a sequence of code lengths (trees.c): one step per symbol, given its length and
- * the next symbol's (0xffff behind the last).  The step says what the walk does here; both users (counting the bit-length
- * symbols, writing them) act on it. */
-enum { RS_NONE = 0, RS_LITERALS, RS_REP16, RS_LIT_REP16, RS_REP17, RS_REP18 };
-struct RunScan {
-    int prevlen, count, max_count, min_count;
-    int emit_count; /* RS_LITERALS: how many times the length itself is coded (1..3); REP*: the repeat count the code carries */
+ * the next symbol's (0xffff behind the last).  A step codes nothing, or 1..3 times the length itself, or a repeat code
+ * (16: previous length 3..6 times, 17: 3..10 zeros, 18: 11..138 zeros), or the length once and then code 16.  The 48 trees
+ * of a wave are in 48 different states, so the step is written without branches (selects only): both users (counting
+ * the bit-length symbols, writing them) run the same instructions for every tree. */
+struct RunScan { int prevlen, count, max_count, min_count; };
+struct RunStep {
+    uint32_t nlit;   /* how many times the length itself is coded here (0..3) */
+    uint32_t rep;    /* 0, or the repeat code that follows (16 / 17 / 18) */
+    uint32_t repcnt; /* the count that code carries */
 };
 __device__ __forceinline__ void run_scan_init(RunScan &r, int firstlen)
 {
-    r.prevlen = -1; r.count = 0; r.max_count = 7; r.min_count = 4; r.emit_count = 0;
-    if (firstlen == 0) { r.max_count = 138; r.min_count = 3; }
+    r.prevlen = -1; r.count = 0;
+    r.max_count = firstlen == 0 ? 138 : 7;
+    r.min_count = firstlen == 0 ? 3 : 4;
 }
-__device__ __forceinline__ int run_scan_step(RunScan &r, int curlen, int nextlen)
+__device__ __forceinline__ RunStep run_scan_step(RunScan &r, int curlen, int nextlen)
 {
-    int act;
-    if (++r.count < r.max_count && curlen == nextlen) return RS_NONE;
-    if (r.count < r.min_count) { act = RS_LITERALS; r.emit_count = r.count; }
-    else if (curlen != 0) {
-        if (curlen != r.prevlen) { act = RS_LIT_REP16; r.emit_count = r.count - 1; }
-        else { act = RS_REP16; r.emit_count = r.count; }
-    } else if (r.count <= 10) { act = RS_REP17; r.emit_count = r.count; }
-    else { act = RS_REP18; r.emit_count = r.count; }
-    r.count = 0;
-    r.prevlen = curlen;
-    if (nextlen == 0) { r.max_count = 138; r.min_count = 3; }
-    else if (curlen == nextlen) { r.max_count = 6; r.min_count = 3; }
-    else { r.max_count = 7; r.min_count = 4; }
-    return act;
+    const int count = r.count + 1;
+    const bool flush = !(count < r.max_count && curlen == nextlen);
+    const bool small = count < r.min_count;
+    const bool lead = curlen != 0 && curlen != r.prevlen; /* a new non-zero length is coded once before it can be repeated */
+    RunStep o;
+    o.nlit = flush ? (small ? (uint32_t)count : (lead ? 1u : 0u)) : 0u;
+    o.rep = (flush && !small) ? (curlen != 0 ? 16u : (count <= 10 ? 17u : 18u)) : 0u;
+    o.repcnt = (uint32_t)(count - (lead ? 1 : 0));
+    r.count = flush ? 0 : count;
+    r.prevlen = flush ? curlen : r.prevlen;
+    const int mx = nextlen == 0 ? 138 : (curlen == nextlen ? 6 : 7);
+    const int mn = (nextlen == 0 || curlen == nextlen) ? 3 : 4;
+    r.max_count = flush ? mx : r.max_count;
+    r.min_count = flush ? mn : r.min_count;
+    return o;
 }
 
 /* blkbase[s] = number of blocks in streams < s (exclusive prefix), blkbase[nstreams] = total */
@@ -314,16 +311,17 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
      * independent reads, and counters are bumped with return-less LDS atomics. */
     int n = 0, max_lcode = -1;
     long static_len = 0, xb_len = 0; /* block cost under the static code / extra bits of the length codes: known from the counts alone */
-    {
-        uint4 fv[HROW / 8];
+    for (int g0 = 0; g0 < HROW / 8; g0 += 12) { /* twelve loads in flight (more would only cost registers: a wave of this kernel must
+                                                 * still find room on a SIMD that other kernels' waves share) */
+        uint4 fv[12];
 #pragma unroll
-        for (int g = 0; g < HROW / 8; g++) fv[g] = fq8[g];
+        for (int g = 0; g < 12; g++) fv[g] = fq8[g0 + g];
 #pragma unroll
-        for (int g = 0; g < HROW / 8; g++) {
+        for (int g = 0; g < 12; g++) {
             const uint32_t fw[4] = {fv[g].x, fv[g].y, fv[g].z, fv[g].w};
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const int sym = 8 * g + j;
+                const int sym = 8 * (g0 + g) + j;
                 if (sym >= LELEMS) continue;
                 const uint32_t f = (sym == 256) ? 1u : ((fw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
                 const int xb = sym >= 257 ? len_extra_bits(sym - 257) : 0;
@@ -344,7 +342,7 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
     for (int i = 0; i < 16; i++) { BLCOUNT(i) = 0; NEXTCODE(i) = 0; }
     for (int it = niter - 1; it >= 0; it--) {
         const uint32_t w = HEAP(n - it);
-        const int L = (int)(w >> 20); /* the root's record still has 0 there */
+        const int L = (int)((w >> 20) & 31u); /* the root's record still has 0 there */
         int bits = L + 1;
         if (bits > 15) { bits = 15; overflow += 2; }
 #pragma unroll
@@ -446,12 +444,11 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
                 const int i = i0 + j;
                 if (i > max_lcode) break;
                 const int curlen = (int)l[j], nextlen = i + 1 <= max_lcode ? (int)l[j + 1] : 0xffff;
-                const int act = run_scan_step(rs, curlen, nextlen);
-                if (act == RS_NONE) continue;
-                if (act == RS_LITERALS) atomicAdd(&BLFREQ(curlen), (uint32_t)rs.emit_count);
-                else if (act == RS_REP16 || act == RS_LIT_REP16) { if (act == RS_LIT_REP16) atomicAdd(&BLFREQ(curlen), 1u); c16++; }
-                else if (act == RS_REP17) c17++;
-                else c18++;
+                const RunStep st = run_scan_step(rs, curlen, nextlen);
+                if (st.nlit) atomicAdd(&BLFREQ(curlen), st.nlit);
+                c16 += st.rep == 16u ? 1u : 0u;
+                c17 += st.rep == 17u ? 1u : 0u;
+                c18 += st.rep == 18u ? 1u : 0u;
             }
         }
         BLFREQ(1) += 2u;
@@ -481,7 +478,7 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
     overflow = 0;
     for (int it = bniter - 1; it >= 0; it--) {
         const uint32_t w = HEAP(bn - it);
-        const int L = (int)(w >> 20);
+        const int L = (int)((w >> 20) & 31u);
         for (int side = 1; side >= 0; side--) {
             const int child = (int)(side ? (w >> 10) & 0x3ffu : w & 0x3ffu);
             int bits = L + 1;
@@ -568,21 +565,19 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
                 const int i = i0 + j;
                 if (i > max_lcode) break;
                 const int curlen = (int)l[j], nextlen = i + 1 <= max_lcode ? (int)l[j + 1] : 0xffff;
-                const int act = run_scan_step(rs, curlen, nextlen);
-                if (act == RS_NONE) continue;
-                const uint32_t cc = ent[j] & 0xffu;
-                const int cl = (int)(ent[j] >> 8);
-                if (act == RS_LITERALS) {
-                    int k = rs.emit_count; /* 1..3 */
-                    do { hw_put(hw, cc, cl); } while (--k != 0);
-                } else if (act == RS_REP16 || act == RS_LIT_REP16) {
-                    if (act == RS_LIT_REP16) hw_put(hw, cc, cl);
-                    hw_put(hw, (e16 & 0xffu) | ((uint32_t)(rs.emit_count - 3) << (e16 >> 8)), (int)(e16 >> 8) + 2);
-                } else if (act == RS_REP17) {
-                    hw_put(hw, (e17 & 0xffu) | ((uint32_t)(rs.emit_count - 3) << (e17 >> 8)), (int)(e17 >> 8) + 3);
-                } else {
-                    hw_put(hw, (e18 & 0xffu) | ((uint32_t)(rs.emit_count - 11) << (e18 >> 8)), (int)(e18 >> 8) + 7);
-                }
+                const RunStep st = run_scan_step(rs, curlen, nextlen);
+                /* everything this step codes, as one bit string (<= 21 bits) */
+                const uint32_t cc = ent[j] & 0xffu, cl = ent[j] >> 8;
+                const uint32_t lit2 = cc | (cc << cl), lit3 = lit2 | (cc << (2u * cl));
+                const uint32_t lits = st.nlit == 0u ? 0u : (st.nlit == 1u ? cc : (st.nlit == 2u ? lit2 : lit3));
+                const uint32_t lbits = st.nlit * cl;
+                const uint32_t er = st.rep == 16u ? e16 : (st.rep == 17u ? e17 : e18);
+                const uint32_t xbits = st.rep == 16u ? 2u : (st.rep == 17u ? 3u : 7u);
+                const uint32_t xval = st.repcnt - (st.rep == 18u ? 11u : 3u);
+                const uint32_t rl = er >> 8;
+                const uint32_t reps = st.rep ? ((er & 0xffu) | (xval << rl)) : 0u;
+                const uint32_t rbits = st.rep ? rl + xbits : 0u;
+                hw_put(hw, lits | (reps << lbits), (int)(lbits + rbits));
             }
         }
         /* the distance tree's two lengths {1, 1}: a run of two, sent as two literals */

@@ -296,11 +296,11 @@ __device__ __forceinline__ uint32_t ring_off(uint32_t x)
     return (x * 0x201u) & 0x3803u;
 }
 template <bool TAIL, bool MIN4, bool COMPLETE>
-__device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int wq, uint32_t lead)
+__device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int wq, uint32_t lead, uint32_t nw /* dwords per piece */)
 {
     /* the window is staged dword-aligned, its first token starts `lead` (< 32) bits in: funnel the piece's dwords
      * once per 32 positions so that every bit offset below is a compile-time constant */
-    const uint32_t *wp = sh.win + tid * (SUBBITS / 32) + (uint32_t)wq;
+    const uint32_t *wp = sh.win + tid * nw + (uint32_t)wq;
     const unsigned long long a01 = ((unsigned long long)wp[1] << 32) | wp[0], a12 = ((unsigned long long)wp[2] << 32) | wp[1];
     const unsigned long long w01 = ((a12 >> lead) << 32) | (uint32_t)(a01 >> lead);
     const unsigned long long w01x4 = w01 << 2; /* index bits pre-scaled to the byte offset of a 4-byte table entry */
@@ -341,7 +341,7 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
         if (TAIL) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                ex[j] = tt[j] >= X_STOP ? X_STOP : (x[j] >= (uint32_t)SUBBITS ? x[j] - (uint32_t)SUBBITS : ex[j]);
+                ex[j] = tt[j] >= X_STOP ? X_STOP : (x[j] >= 32u * nw ? x[j] - 32u * nw : ex[j]);
         }
         if (!MIN4) {
             /* tokens shorter than 4 bits land inside this group of four, on a position whose exit is not in LDS yet:
@@ -357,10 +357,10 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
     }
 }
 template <bool MIN4, bool COMPLETE>
-__device__ __forceinline__ void piece_exit_lds(ParShared &sh, uint32_t tid, uint32_t lead)
+__device__ __forceinline__ void piece_exit_lds(ParShared &sh, uint32_t tid, uint32_t lead, uint32_t nw)
 {
-    piece_exit_word<true, MIN4, COMPLETE>(sh, tid, SUBBITS / 32 - 1, lead);
-    for (int wq = SUBBITS / 32 - 2; wq >= 0; wq--) piece_exit_word<false, MIN4, COMPLETE>(sh, tid, wq, lead);
+    piece_exit_word<true, MIN4, COMPLETE>(sh, tid, (int)nw - 1, lead, nw);
+    for (int wq = (int)nw - 2; wq >= 0; wq--) piece_exit_word<false, MIN4, COMPLETE>(sh, tid, wq, lead, nw);
 }
 
 
@@ -786,7 +786,8 @@ __device__ __forceinline__ StreamView make_view(const uint8_t *rec, uint64_t rec
 template <int MODE>
 __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView &sv, int tid, unsigned long long *dbg,
                                                  const ScratchOut &so /* MODE_SCRATCH only */,
-                                                 HdrCache *hc /* NULL, or this block's decoded-header row */, uint32_t hctag)
+                                                 HdrCache *hc /* NULL, or this block's decoded-header row */, uint32_t hctag,
+                                                 uint32_t hint_end = 0xffffffffu /* payload bit where the block probably ends */)
 {
     constexpr bool WRITE = MODE == MODE_FINAL;
     uint32_t widx = 0; /* window number inside the block */
@@ -911,20 +912,28 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
     for (;;) {
         if (dbg && tid == 0) sh.acc[11]++;
         const uint32_t wcur = sh.cur;
-        const uint32_t wlead = stage_bits(sh.win, WIN_WORDS, sv.rec, sv.reclen, sv.paybit0, wcur);
+        /* Piece size of this window: a window's time is ONE lane's serial work on its piece, whatever the number of pieces
+         * that hold tokens.  When the block probably ends inside the window (the next candidate's start bit is the hint),
+         * what is left of it is spread over all PT lanes in pieces of fewer dwords.  A wrong hint costs time, not
+         * correctness: too small and the block simply continues in the next window, too large and pieces are as long as
+         * they would have been without it. */
+        uint32_t nw = SUBBITS / 32;
+        if (hint_end > wcur && hint_end - wcur < (uint32_t)WINBITS) nw = (hint_end - wcur + (uint32_t)PT * 32u - 1u) / ((uint32_t)PT * 32u); /* 1..8 */
+        const uint32_t sub = 32u * nw;
+        const uint32_t wlead = stage_bits(sh.win, (int)((uint32_t)PT * nw) + 8, sv.rec, sv.reclen, sv.paybit0, wcur);
         __syncthreads();
         PHASE(1);
-        const uint32_t pstart = wlead + (uint32_t)tid * SUBBITS;
-        const uint32_t limit = pstart + SUBBITS;
+        const uint32_t pstart = wlead + (uint32_t)tid * sub;
+        const uint32_t limit = pstart + sub;
         uint32_t entry;
         {
             /* P1: exit values of my piece -> my column of sh.ring (rows 0..23 = exit function) */
             if (sh.complete) {
-                if (sh.mintok >= 4u) piece_exit_lds<true, true>(sh, (uint32_t)tid, wlead);
-                else piece_exit_lds<false, true>(sh, (uint32_t)tid, wlead);
+                if (sh.mintok >= 4u) piece_exit_lds<true, true>(sh, (uint32_t)tid, wlead, nw);
+                else piece_exit_lds<false, true>(sh, (uint32_t)tid, wlead, nw);
             } else {
-                if (sh.mintok >= 4u) piece_exit_lds<true, false>(sh, (uint32_t)tid, wlead);
-                else piece_exit_lds<false, false>(sh, (uint32_t)tid, wlead);
+                if (sh.mintok >= 4u) piece_exit_lds<true, false>(sh, (uint32_t)tid, wlead, nw);
+                else piece_exit_lds<false, false>(sh, (uint32_t)tid, wlead, nw);
             }
             PHASE(2);
             /* P2: resolve every piece's entry offset.  Composing whole functions (24 look-ups each) in a scan
@@ -1372,7 +1381,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                                                   const uint32_t *__restrict__ candbase, Cand *__restrict__ cands,
                                                   uint8_t *__restrict__ scratch, uint32_t *__restrict__ scratch_top, uint32_t scratch_cap16,
                                                   HdrCache *__restrict__ hdrs, uint32_t calltag, uint32_t *__restrict__ jobctr,
-                                                  unsigned long long *__restrict__ dbg)
+                                                  unsigned long long *__restrict__ dbg, uint32_t use_hint)
 {
     /* static LDS (below the 64 KiB static limit): the compiler folds the structure's address into the instructions' offset
      * fields; with a dynamic allocation every LDS access of the hot loops paid an extra address add */
@@ -1396,10 +1405,21 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         const StreamView sv = make_view(rec, reclen, d, nullptr);
         if (tid == 0) { sh.cur = c->bit; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
         if (dbg && tid == 0) { for (int i = 0; i < 20; i++) sh.acc[i] = 0; sh.tp = (unsigned long long)clock64(); }
-        __syncthreads();
+        /* where the block probably ends: the nearest candidate behind it (decode_one_block sizes its pieces by that) */
+        uint32_t hint;
+        {
+            const uint32_t mybit = c->bit, nc = candbase[s + 1] - candbase[s];
+            uint32_t m = 0xffffffffu;
+            for (uint32_t j = tid; j < nc; j += PT) {
+                const uint32_t b = cands[(size_t)s * MAXCAND + j].bit;
+                if (b > mybit && b < m) m = b;
+            }
+            hint = block_min_pt(m, sh.scan_a); /* (its barriers also publish the lines above) */
+            if (!use_hint) hint = 0xffffffffu;
+        }
         ScratchOut so;
         so.base = scratch; so.top = scratch_top; so.cap16 = scratch_cap16; so.wbase = c->wbase; so.wlen = c->wlen;
-        decode_one_block<MODE_SCRATCH>(sh, sv, tid, dbg, so, hdrs + ((size_t)s * MAXCAND + ci), hdr_tag(calltag, c->bit));
+        decode_one_block<MODE_SCRATCH>(sh, sv, tid, dbg, so, hdrs + ((size_t)s * MAXCAND + ci), hdr_tag(calltag, c->bit), hint);
         __syncthreads();
         if (tid == 0) {
             const bool ok = (sh.status == 0 || sh.status == 1) && sh.cur > c->bit;

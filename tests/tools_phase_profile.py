@@ -1,5 +1,6 @@
 """Developer tool (GPU): in-kernel phase breakdown of the parallel inflate for one heavy stream."""
 import ctypes, sys, os
+import sys as _s
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from datacompressionfloat_amd import MrcZipCodec
@@ -8,14 +9,14 @@ n = 16 * 6291456
 g = torch.Generator(device="cuda").manual_seed(1234)
 x = torch.empty(n, dtype=torch.float32, device="cuda").normal_(10.0, 3.0, generator=g).view(torch.int32)
 c = MrcZipCodec(0, 16)
-rec, _ = c.compress_device(x, 8, 1)
+BITS = int(_s.argv[2]) if len(_s.argv) > 2 else 8
+rec, _ = c.compress_device(x, BITS, 1)
 _LIB.mrcz_debug_inflate_phases.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
-import sys as _s
 MODE = int(_s.argv[1]) if len(_s.argv) > 1 else 1   # 1 = sequential-chain kernel, 2 = block-parallel kernels (count rows, then write rows)
 _LIB.mrcz_debug_inflate_phases(c._ctx, MODE, 0, None)
 out, _ = c.uncompress_device(rec, n)
 names = ["hdr", "stage", "P1 exitfn", "P2 compose", "P3 walk", "P3 scans", "P4 scatter", "P4 wait", "fill+flush", "-"]
-for s in ((4, 5, 6, 7) if MODE == 1 else (6, 7)):
+for s in ((4, 5, 6, 7) if MODE == 1 else (5, 6, 7)):
     buf = (ctypes.c_uint64 * 20)()
     _LIB.mrcz_debug_inflate_phases(c._ctx, MODE, s, buf)
     v = list(buf)
