@@ -827,6 +827,21 @@ extern "C" int mrcz_debug_inflate_phases(mrcz_ctx_t *ctx, int enable, uint32_t s
     return MRCZ_OK;
 }
 
+extern "C" int mrcz_debug_candidates(mrcz_ctx_t *ctx, uint64_t out[2])
+{
+    if (!ctx || !out) return MRCZ_EINVAL;
+    uint32_t raw[RAW_SEGS];
+    if (hipMemcpy(raw, ctx->njobs + 4, sizeof(raw), hipMemcpyDeviceToHost) != hipSuccess) return MRCZ_EHIP;
+    out[0] = 0;
+    for (uint32_t g = 0; g < RAW_SEGS; g++) out[0] += raw[g];
+    out[1] = 0;
+    uint32_t nc[512];
+    const uint32_t ns = 4u * (ctx->max_chunks < 128u ? ctx->max_chunks : 128u);
+    if (hipMemcpy(nc, ctx->ncand, ns * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return MRCZ_EHIP;
+    for (uint32_t s = 0; s < ns; s++) out[1] += nc[s];
+    return MRCZ_OK;
+}
+
 extern "C" int64_t mrcz_debug_fallbacks(const mrcz_ctx_t *ctx) { return ctx ? (int64_t)ctx->last_fallbacks : -1; }
 
 extern "C" int mrcz_debug_blocks(mrcz_ctx_t *ctx, uint32_t stream, mrcz_block_info_t *blocks, uint32_t max_blocks)

@@ -1229,8 +1229,14 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
      * candidate's 256 bytes into its own LDS column (64 independent loads), then parses from there. */
     __shared__ uint32_t hw[VH_WORDS * 64];
     __shared__ uint8_t vlut[128 * 64];
-    __shared__ uint8_t vlens[320 * 64]; /* decoded code lengths, one column per lane: handed to the count / write passes */
+    /* decoded code lengths, one ROW per lane (81 dwords: an odd stride, so the lanes' rows start in different banks):
+     * handed to the count / write passes.  Rows are zeroed up front and only non-zero lengths are written, so a run
+     * of zeros -- up to 138 lengths per symbol, and the garbage a false candidate decodes is full of them -- costs
+     * nothing, and the wave does not wait in every step for the lane with the longest run. */
+    constexpr uint32_t VROW = 81;
+    __shared__ uint32_t vlens32[VROW * 64];
     const int lane = threadIdx.x;
+    uint8_t *vrow = reinterpret_cast<uint8_t *>(vlens32 + VROW * (uint32_t)lane);
     const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
     const uint64_t nrec32 = reclen >> 2;
     /* the raw list comes in RAW_SEGS segments: flat index -> (segment, offset) through the counts' prefix sums */
@@ -1252,7 +1258,7 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
         const uint64_t g0 = d.payoff * 8ull + p;
         const uint32_t paybits = d.paylen * 8u;
         const uint64_t wbase = g0 >> 5;
-#pragma unroll 8
+#pragma unroll 16
         for (int w = 0; w < VH_WORDS; w++) {
             const uint64_t wi = wbase + (uint64_t)w;
             uint32_t v = 0;
@@ -1262,6 +1268,8 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
             }
             hw[w * 64 + lane] = v;
         }
+#pragma unroll
+        for (uint32_t k = 0; k < VROW - 1u; k++) vlens32[VROW * (uint32_t)lane + k] = 0;
         /* n <= 25 bits at global bit position g: from the lane's LDS column when staged, else from memory */
         auto gbits = [&](const uint8_t *, uint64_t, uint64_t g, int n) -> uint32_t {
             const uint64_t q = g - (wbase << 5);
@@ -1274,19 +1282,27 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
         };
         const uint32_t nlen = gbits(rec, reclen, g0 + 3, 5) + 257u, ndist = gbits(rec, reclen, g0 + 8, 5) + 1u;
         const uint32_t ncode = gbits(rec, reclen, g0 + 13, 4) + 4u;
-        /* code-length code: canonical codes of <= 7 bits -> first-code/offset arrays in registers */
         /* code-length code (<= 7 bits): canonical codes -> the lane's private 128-entry table in LDS (sym | len << 5).
          * Per-length counters are 8-bit fields of one 64-bit register (no dynamically indexed register arrays). */
         uint32_t bl[19];
 #pragma unroll
         for (int i = 0; i < 19; i++) bl[i] = 0;
         unsigned long long cnt = 0;
+        {
+            /* HCLEN + 4 lengths of 3 bits: 57 bits at most, from one 64-bit window */
+            const uint64_t q = g0 + 17 - (wbase << 5);
+            const uint32_t i0 = (uint32_t)(q >> 5), sh0 = (uint32_t)q & 31u;
+            const uint32_t a0 = hw[i0 * 64 + lane], a1 = hw[(i0 + 1u) * 64 + lane], a2 = hw[(i0 + 2u) * 64 + lane];
+            const unsigned long long lo = ((unsigned long long)a0 | ((unsigned long long)a1 << 32)) >> sh0;
+            const unsigned long long hi = sh0 ? ((unsigned long long)a2 << (64u - sh0)) : 0ull;
+            const unsigned long long bits = lo | hi;
 #pragma unroll
-        for (int i = 0; i < 19; i++) {
-            if ((uint32_t)i < ncode) {
-                const uint32_t l = gbits(rec, reclen, g0 + 17 + 3u * (uint32_t)i, 3);
-                bl[k_bl_order(i)] = l;
-                cnt += 1ull << (8u * l);
+            for (int i = 0; i < 19; i++) {
+                if ((uint32_t)i < ncode) {
+                    const uint32_t l = (uint32_t)(bits >> (3 * i)) & 7u;
+                    bl[k_bl_order(i)] = l;
+                    cnt += 1ull << (8u * l);
+                }
             }
         }
         unsigned long long next = 0; /* next code of each length */
@@ -1314,26 +1330,46 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
                 }
             }
         }
-        uint64_t pos = g0 + 17 + 3ull * ncode;
         const uint32_t total_l = nlen + ndist;
         uint32_t idx = 0, kraft = 0, prev = 0, eoblen = 0;
+        /* The symbols: a 64-bit bit buffer refilled from the lane's LDS column (the refill address only depends on how
+         * many words were taken, so it is off the dependent chain: one table read per symbol is what a step waits for). */
+        const uint64_t q0 = g0 + 17 + 3ull * ncode - (wbase << 5); /* bit inside the staged words */
+        uint32_t wi = (uint32_t)(q0 >> 5);
+        uint32_t used = (uint32_t)q0;                                /* bits consumed, relative to the staged words */
+        unsigned long long buf = 0;
+        int nb = 0;
+        if (wi + 1u < (uint32_t)VH_WORDS) {
+            buf = ((unsigned long long)hw[wi * 64 + lane] | ((unsigned long long)hw[(wi + 1u) * 64 + lane] << 32)) >> (used & 31u);
+            nb = 64 - (int)(used & 31u);
+            wi += 2;
+        } else ok = false; /* (cannot happen: the code-length code ends inside the first four words) */
+        const uint32_t pay_end = paybits - p; /* bits from the candidate's start to the end of the payload */
+        const uint32_t used0 = (uint32_t)(g0 - (wbase << 5));
         while (ok && idx < total_l) {
-            if (pos - d.payoff * 8ull + 14u > paybits) { ok = false; break; }
-            const uint32_t v = gbits(rec, reclen, pos, 14);
+            if (nb < 32) {
+                const uint32_t w = wi < (uint32_t)VH_WORDS ? hw[wi * 64 + lane]
+                                                            : (uint32_t)mrcz::gbits(rec, reclen, (wbase + wi) << 5, 16) | ((uint32_t)mrcz::gbits(rec, reclen, ((wbase + wi) << 5) + 16, 16) << 16);
+                buf |= (unsigned long long)w << nb;
+                nb += 32;
+                wi++;
+            }
+            if (used - used0 + 14u > pay_end) { ok = false; break; }
+            const uint32_t v = (uint32_t)buf & 0x3fffu;
             const uint32_t e = vlut[(v & 127u) * 64u + (uint32_t)lane];
             const uint32_t l = e >> 5, sym = e & 31u;
-            pos += l;
-            uint32_t rep = 1, val = sym;
-            if (sym == 16u) { if (idx == 0) { ok = false; break; } val = prev; rep = 3u + ((v >> l) & 3u); pos += 2; }
-            else if (sym == 17u) { val = 0; rep = 3u + ((v >> l) & 7u); pos += 3; }
-            else if (sym == 18u) { val = 0; rep = 11u + ((v >> l) & 127u); pos += 7; }
+            uint32_t rep = 1, val = sym, take = l;
+            if (sym == 16u) { if (idx == 0) { ok = false; break; } val = prev; rep = 3u + ((v >> l) & 3u); take += 2; }
+            else if (sym == 17u) { val = 0; rep = 3u + ((v >> l) & 7u); take += 3; }
+            else if (sym == 18u) { val = 0; rep = 11u + ((v >> l) & 127u); take += 7; }
+            buf >>= take; nb -= (int)take; used += take;
             if (idx + rep > total_l) { ok = false; break; }
             /* the lengths at [idx, idx + rep) that belong to the literal/length code */
             const uint32_t lo = idx < nlen ? idx : nlen, hi = idx + rep < nlen ? idx + rep : nlen;
             if (val) kraft += (hi - lo) * (32768u >> val);
             if (lo <= 256u && 256u < hi) eoblen = val;
             if (kraft > 32768u) { ok = false; break; } /* over-subscribed: no code */
-            for (uint32_t k = 0; k < rep; k++) vlens[(idx + k) * 64u + (uint32_t)lane] = (uint8_t)val;
+            if (val) for (uint32_t k = 0; k < rep; k++) vrow[idx + k] = (uint8_t)val; /* <= 6 */
             idx += rep;
             prev = val;
         }
@@ -1343,15 +1379,9 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
                 Cand cnd; cnd.bit = p; cnd.end = 0; cnd.nout = 0; cnd.info = 0; cands[(size_t)s * MAXCAND + i] = cnd;
                 HdrCache *hc = hdrs + ((size_t)s * MAXCAND + i);
                 uint32_t *dst = reinterpret_cast<uint32_t *>(hc->lens);
-                for (uint32_t k = 0; k < (total_l + 3u) / 4u; k++) {
-                    uint32_t w = 0;
-#pragma unroll
-                    for (uint32_t b = 0; b < 4u; b++)
-                        if (4u * k + b < total_l) w |= (uint32_t)vlens[(4u * k + b) * 64u + (uint32_t)lane] << (8u * b);
-                    dst[k] = w;
-                }
+                for (uint32_t k = 0; k < (total_l + 3u) / 4u; k++) dst[k] = vlens32[VROW * (uint32_t)lane + k]; /* (lengths behind total_l are zero) */
                 hc->bfinal = 0; hc->nlen = nlen; hc->ndist = ndist;
-                hc->cur_after = (uint32_t)(pos - d.payoff * 8ull);
+                hc->cur_after = p + (used - used0);
                 hc->valid = hdr_tag(calltag, p);
             }
         }

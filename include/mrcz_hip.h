@@ -205,6 +205,13 @@ int64_t mrcz_debug_fallbacks(const mrcz_ctx_t *ctx);
  * [11] windows [12..16] header sub-phases (first bits, code-length code, length decode, literal
  * table, distance table). */
 int mrcz_debug_inflate_phases(mrcz_ctx_t *ctx, int enable, uint32_t stream, uint64_t out[20]);
+/* (enable = 3 switches on the phase clocks of the Huffman construction kernel instead: out[0..7] of stream 0 = the slowest
+ * tree's clocks per phase, out[16..19] of stream 0 and out[0..3] of stream 1 = their sums, out[12] of stream 1 = trees;
+ * tests/tools_huff_profile.py prints them.) */
+
+/* Inspection (profiling): block-start candidates of the last batch of the last mrcz_uncompress_chunks call:
+ * out[0] = positions that passed the signature scan and went to header validation, out[1] = validated candidates. */
+int mrcz_debug_candidates(mrcz_ctx_t *ctx, uint64_t out[2]);
 
 #ifdef __cplusplus
 }

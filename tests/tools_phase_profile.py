@@ -23,3 +23,8 @@ for s in ((4, 5, 6, 7) if MODE == 1 else (5, 6, 7)):
     tot = sum(v[:10]) + sum(v[12:20])
     print(f"stream {s} (plane {s % 4}): blocks={v[10]} windows={v[11]} total={tot / 1e8:.2f} ms@100MHz " +
           " ".join(f"{names[i]}={100.0 * v[i] / max(tot, 1):.1f}%" for i in range(9)) + " | hdr: " + " ".join(f"{n}={100.0 * v[12 + i] / max(tot, 1):.1f}%" for i, n in enumerate(["first", "blcode", "lens-write+sync", "lit", "dist", "lens-exitfn", "lens-compose", "lens-count"])) + f" rest={100.0 * v[0] / max(tot, 1):.1f}%")
+
+cnt = (ctypes.c_uint64 * 2)()
+_LIB.mrcz_debug_candidates.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+_LIB.mrcz_debug_candidates(c._ctx, cnt)
+print(f"candidates: {cnt[0]} passed the signature scan, {cnt[1]} validated ({n // 6291456} chunks)")
