@@ -1726,15 +1726,25 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
     const uint32_t ns = nseg[s];
     SegBases sb;
     sb.rec = rec; sb.scratch = scratch; sb.planes = planes; sb.reclen = reclen; sb.planes_bytes = planes_bytes;
+    /* nearly every tile lies in one segment or two: both are fetched with wave-uniform (scalar) loads.  Tile -> segment number
+     * -> segment -> data is a chain of three memory round trips, so the segments of the NEXT tile are looked up while this
+     * tile's data is in flight. */
+    Seg ZS;
+    ZS.src = 0; ZS.dst = 0; ZS.len = 0; ZS.fill_until = 0; ZS.fillb = 0;
+    uint32_t k0n = 0;
+    Seg An = ZS, Bn = ZS;
+    if ((uint64_t)blockIdx.x * MTILE < n) {
+        k0n = ns ? (uint32_t)__builtin_amdgcn_readfirstlane((int)segidx[(size_t)s * MTILES + blockIdx.x]) : 0u;
+        if (k0n < ns) An = sg[k0n];
+        if (k0n + 1u < ns) Bn = sg[k0n + 1u];
+    }
     for (uint32_t t = blockIdx.x; (uint64_t)t * MTILE < n; t += gridDim.x) {
         const uint32_t p0 = t * MTILE, pend = (n - p0) < (uint32_t)MTILE ? n : p0 + MTILE;
-        /* nearly every tile lies in one segment or two: both are fetched with wave-uniform (scalar) loads */
-        const uint32_t k0 = ns ? (uint32_t)__builtin_amdgcn_readfirstlane((int)segidx[(size_t)s * MTILES + t]) : 0u;
-        Seg A, B;
-        A.src = 0; A.dst = 0; A.len = 0; A.fill_until = 0; A.fillb = 0;
-        B = A;
-        if (k0 < ns) A = sg[k0];
-        if (k0 + 1u < ns) B = sg[k0 + 1u];
+        const uint32_t k0 = k0n;
+        const Seg A = An, B = Bn;
+        const uint32_t tn = t + gridDim.x;
+        const bool more = (uint64_t)tn * MTILE < n;
+        if (more) k0n = ns ? (uint32_t)__builtin_amdgcn_readfirstlane((int)segidx[(size_t)s * MTILES + tn]) : 0u;
         const uint8_t *abase = seg_base(sb, A.src), *bbase = seg_base(sb, B.src);
         const uint32_t aend = A.dst + A.len, bend = B.dst + B.len;
         /* A group of 16 bytes that straddles the boundary A | B (one per boundary) is read twice -- once relative to each
@@ -1760,6 +1770,9 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
             if (kd == 2u) __builtin_memcpy(&v[j], bbase + (p - B.dst), 16);
             if (kd == 3u) __builtin_memcpy(&v2, bbase + ((int64_t)p - (int64_t)B.dst), 16);
         }
+        An = ZS; Bn = ZS;
+        if (more && k0n < ns) An = sg[k0n];
+        if (more && k0n + 1u < ns) Bn = sg[k0n + 1u];
 #pragma unroll
         for (int j = 0; j < MTILE / 16 / 64; j++) {
             const uint32_t g = (uint32_t)lane + 64u * (uint32_t)j, p = p0 + 16u * g;
