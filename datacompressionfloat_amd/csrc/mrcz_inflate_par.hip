@@ -72,9 +72,16 @@ struct HuffDecD : HuffAuxT<32> {
  * token tables, so that a walk step is ONE LDS read.  tok[idx], idx = next LBITS stream bits:
  *   bits  0..7   total bits of the token when idx determines them (1..MAXTOK), X_EOB, X_ERR; 0 = general path
  *   bits  8..16  plane bytes the token produces (1 literal, 3..258 match), TOK_NOTD1 = match with distance != 1
- *   bits 17..25  literal/length symbol, bits 26..29 its code length (0 = code longer than LBITS) */
+ *   bits 17..25  literal/length symbol, bits 26..29 its code length (0 = code longer than LBITS)
+ * A LITERAL whose successor is a literal too, both codes inside the LBITS index bits, may carry the second one as well
+ * (blocks of short codes: the exponent plane, a mantissa plane masked down to a few bits): bit 30 marks such an entry,
+ * bits 9..16 = the second byte, and bits 26..29 hold the SECOND code's length (the first one's is the token's bits).  Byte 0
+ * stays the FIRST token's bits, so the exit functions (which must see every token start) read the table as before; the two
+ * walks take both literals in one step when the second one starts inside their piece. */
 constexpr uint32_t TOK_NOTD1 = 0x1ffu;
 constexpr int TOK_SYM_SHIFT = 17, TOK_LEN_SHIFT = 26;
+constexpr uint32_t TOK_PAIR = 1u << 30;
+__device__ __forceinline__ uint32_t tok_second_len(uint32_t e) { return (e & TOK_PAIR) ? (e >> TOK_LEN_SHIFT) & 15u : 0u; }
 
 
 struct ParShared {
@@ -104,6 +111,7 @@ struct ParShared {
     uint32_t lead;      /* scratch mode: bytes the block produces before its first literal */
     uint32_t nwin;      /* windows of the current block so far */
     unsigned long long acc[20], tp; /* phase counters (profiling builds of the call only) */
+    uint32_t dbl;       /* enough table entries carry a second literal for the walks to look for it (block of short codes) */
     uint32_t complete;  /* every entry of the token table carries its token's bits (no entry says "ask token_bits()") */
     uint32_t dmax;      /* longest distance code + extra bits of the current block */
     uint32_t mintok;    /* shortest literal/length code of the current block (every token is at least that long) */
@@ -226,7 +234,9 @@ __device__ __forceinline__ uint32_t base_dist_of(int dc) /* dc 0..29 */
 __device__ __forceinline__ uint32_t huff_decode_lit(const ParShared &sh, uint32_t v)
 {
     const uint32_t e = sh.tok[v & ((1u << LBITS) - 1u)];
-    if (e >> TOK_LEN_SHIFT) return ((e >> TOK_SYM_SHIFT) & 511u) | ((e >> TOK_LEN_SHIFT) << 16);
+    if (e & TOK_PAIR) return ((e >> TOK_SYM_SHIFT) & 255u) | ((e & 0xffu) << 16); /* two literals: the first one's code length is the token's bits */
+    const uint32_t l = (e >> TOK_LEN_SHIFT) & 15u;
+    if (l) return ((e >> TOK_SYM_SHIFT) & 511u) | (l << 16);
     return huff_decode_long<LBITS>(sh.lit, v);
 }
 /* byte 0 of a tok entry (token bits) */
@@ -384,7 +394,7 @@ struct SubResult {
 /* P3: count walk.  Decode tokens from window bit `start` until the position reaches `limit` (or
  * END_BLOCK), counting the plane bytes they produce.  Nearly every token is sized by the two fast
  * tables (token bits, produced bytes) with a single 12-bit lookup each. */
-template <bool TRACK_LAST, bool STOP_AT_LIT = false>
+template <bool TRACK_LAST, bool STOP_AT_LIT = false, bool DBL = false>
 __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t start, uint32_t limit)
 {
     SubResult r;
@@ -398,7 +408,21 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
         if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
         const uint32_t idx = (uint32_t)buf & ((1u << LBITS) - 1u);
         const uint32_t e = sh.tok[idx];
-        const uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
+        const uint32_t t = e & 0xffu;
+        uint32_t n = (e >> 8) & 0x1ffu;
+        if (DBL) {
+            const uint32_t l2 = tok_second_len(e);
+            if (l2) {
+                if (STOP_AT_LIT) break;
+                n = 1u;
+                if (pos + t < limit) { /* the second literal starts inside this piece: both in one step */
+                    buf >>= t + l2; nb -= (int)(t + l2); pos += t + l2;
+                    r.nout += 2u;
+                    if (TRACK_LAST) r.lastlit = 0x100u | ((e >> 9) & 0xffu);
+                    continue;
+                }
+            }
+        }
         if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) { /* 1 <= t <= MAXTOK, distance 1 */
             if (STOP_AT_LIT && n == 1u) break;
             buf >>= t; nb -= (int)t; pos += t;
@@ -480,6 +504,7 @@ __device__ __noinline__ uint32_t walk_general_token(const ParShared &sh, uint32_
  * time into a 64-bit register and stored with (generally unaligned) dword stores -- gfx9 global memory takes them.  One code
  * path for literals and runs: the lanes of a wave, which hold different token kinds in every iteration, do not serialise
  * through two branches. */
+template <bool DBL>
 __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, uint32_t limit, uint8_t *out, uint32_t last)
 {
     uint32_t pos = start;
@@ -494,8 +519,17 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
         if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
         const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
         uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
+        uint32_t pair = 0; /* two literals taken in one step: first | second << 8 */
+        if (DBL) {
+            const uint32_t l2 = tok_second_len(e);
+            if (l2) {
+                n = 1u;
+                if (pos + t < limit) { t += l2; n = 2u; pair = ((e >> TOK_SYM_SHIFT) & 0xffu) | (((e >> 9) & 0xffu) << 8) | 0x10000u; }
+            }
+        }
         if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) {
             if (n == 1u) last = (e >> TOK_SYM_SHIFT) & 0xffu;
+            if (DBL && pair) last = (pair >> 8) & 0xffu;
             buf >>= t; nb -= (int)t; pos += t;
         } else {
             const uint32_t g = walk_general_token(sh, pos);
@@ -508,7 +542,7 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
             nb = 64 - (int)(pos & 31u);
             wi += 2;
         }
-        const uint32_t pat = last * 0x01010101u;
+        const uint32_t pat = (DBL && pair) ? (pair & 0xffffu) : last * 0x01010101u;
         if (n >= 48u) {
             /* long run: bytes up to a 16-byte boundary, then whole 16-byte stores; the rest below */
             uint32_t head = (16u - (uint32_t)(((uintptr_t)p + fill) & 15u)) & 15u;
@@ -791,7 +825,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
 {
     constexpr bool WRITE = MODE == MODE_FINAL;
     uint32_t widx = 0; /* window number inside the block */
-    if (tid == 0) { sh.nwin = 0; sh.lead = 0; }
+    if (tid == 0) { sh.nwin = 0; sh.lead = 0; sh.dbl = 0; }
     const bool hdr_cached = hc != nullptr && hc->valid == hctag;
     if (hdr_cached) {
         if (tid == 0) { sh.btype = 2; sh.bfinal = hc->bfinal; sh.nlen = hc->nlen; sh.ndist = hc->ndist; sh.cur = hc->cur_after; }
@@ -880,13 +914,38 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
     PHASE(15);
     huff_build<0, 9>(sh.dist, sh.lens + sh.nlen, (int)sh.ndist, tid, sh.dist.lut, DBITS);
     PHASE(16);
-    if (tid == 0) sh.complete = 1; /* (the last barrier of huff_build is behind us; the one below publishes the verdict) */
+    if (tid == 0) sh.complete = 1; /* (the last barrier of huff_build is behind us; the ones below publish the verdict) */
     bool anyzero = false;
-    for (int i = tid; i < (1 << LBITS); i += PT) {
-        uint32_t nby;
-        const uint32_t t = fast_token_entry(sh, (uint32_t)i, &nby);
-        sh.tok[i] |= t | (nby << 8);
-        anyzero |= t == 0u;
+    {
+        /* every entry is computed from the symbol / code length fields huff_build left (read phase), then written */
+        constexpr int EPT = (1 << LBITS) / PT;
+        uint32_t add[EPT], second[EPT];
+        uint32_t ndbl = 0;
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)(k * PT);
+            uint32_t nby;
+            const uint32_t t = fast_token_entry(sh, i, &nby);
+            add[k] = t | (nby << 8);
+            second[k] = 0;
+            anyzero |= t == 0u;
+            if (nby == 1u && t < (uint32_t)LBITS) { /* a literal: is the token behind it a literal inside the index bits too? */
+                const uint32_t e2 = sh.tok[i >> t];
+                const uint32_t l2 = e2 >> TOK_LEN_SHIFT, sym2 = (e2 >> TOK_SYM_SHIFT) & 511u;
+                if (l2 != 0u && t + l2 <= (uint32_t)LBITS && sym2 < 256u) { second[k] = TOK_PAIR | (l2 << TOK_LEN_SHIFT) | (sym2 << 9); ndbl++; }
+            }
+        }
+        if (ndbl) atomicAdd(&sh.dbl, ndbl);
+        __syncthreads();
+        /* worth the walks' extra test when a quarter of the patterns are pairs; otherwise the table stays as the plain walks read it */
+        const bool pairs = sh.dbl >= (1u << LBITS) / 4u;
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const uint32_t e = sh.tok[tid + k * PT] | add[k];
+            sh.tok[tid + k * PT] = (pairs && second[k]) ? ((e & ~(15u << TOK_LEN_SHIFT)) | second[k]) : e;
+        }
+        __syncthreads();
+        if (tid == 0) sh.dbl = pairs ? 1u : 0u;
     }
     /* longest token of this block: bounds the exit-function domain */
     if (tid == 0) { sh.dmax = 0; sh.maxtok = 1; sh.mintok = 15; }
@@ -975,7 +1034,8 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         PHASE(3);
         /* P3: walk from the true entry, counting */
         SubResult r;
-        if (start != POS_INVALID) r = count_walk<true>(sh, start, limit);
+        const bool dbl = sh.dbl != 0u; /* (block-uniform) */
+        if (start != POS_INVALID) r = dbl ? count_walk<true, false, true>(sh, start, limit) : count_walk<true>(sh, start, limit);
         else { r.land = POS_INVALID; r.nout = 0; r.flags = 0; r.lastlit = 0; } /* behind END_BLOCK or behind a token the walk of an earlier lane flags */
         PHASE(4);
         /* first lane that ended the block (or failed); lanes after it are inactive */
@@ -1027,10 +1087,13 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
                 /* the bytes in front of the block's first literal replicate the previous block's last byte, which is
                  * not known here: remember how many there are, k_blk_gather fills them in */
                 const uint32_t fl = block_min_pt((active && r.lastlit) ? (uint32_t)tid : 0xffffffffu, sh.scan_a);
-                if ((uint32_t)tid == fl) sh.lead = op + myoff + count_walk<false, true>(sh, start, limit).nout;
+                if ((uint32_t)tid == fl) sh.lead = op + myoff + (dbl ? count_walk<false, true, true>(sh, start, limit).nout : count_walk<false, true>(sh, start, limit).nout);
             }
         } else wout = sv.out + op + myoff;
-        if (active && r.nout) write_walk(sh, start, limit, wout, before ? (before & 0xffu) : lastin);
+        if (active && r.nout) {
+            if (dbl) write_walk<true>(sh, start, limit, wout, before ? (before & 0xffu) : lastin);
+            else write_walk<false>(sh, start, limit, wout, before ? (before & 0xffu) : lastin);
+        }
         PHASE(6);
         if (tid == PT - 1) {
             const uint32_t lw = (active && r.lastlit) ? r.lastlit : before;
