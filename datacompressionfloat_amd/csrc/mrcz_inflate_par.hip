@@ -999,15 +999,22 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
              * is 24x redundant; instead the wave walks its 64 functions as a chain.  Pass 1: lane k < 24 of each
              * 32-lane half follows entry offset k through the half's 32 pieces (the function of piece i is a
              * broadcast LDS read), which yields the half's and then the wave's exit function.  After the waves'
-             * functions are chained (one barrier), pass 2 walks the same chain from the now known entry and
-             * lane i keeps the value in front of piece i. */
+             * functions are chained (one barrier), pass 2 reads the chain from the now known entry off the lane that followed
+             * exactly that entry in pass 1. */
             const int l = lane_id(), k = l & 31;
             const uint8_t *hf = reinterpret_cast<const uint8_t *>(&sh.ring[0][(tid & ~63) | (l & 32)]); /* first piece of my half */
             __builtin_amdgcn_wave_barrier();
+            /* Pass 1 keeps what it sees: traj byte i = where the chain that enters the half at offset k stands in front of piece i
+             * (5-bit values, four to a register; the loop is unrolled so that every byte position is a constant).  Pass 2 then
+             * needs no second walk: the chain from the half's true entry e is lane e's trajectory, fetched with eight
+             * independent cross-lane reads instead of 32 dependent LDS reads. */
+            uint32_t traj[8];
             uint32_t v = k < MAXTOK ? (uint32_t)k : (uint32_t)X_ERR;
-#pragma unroll 4
-            for (int i = 0; i < 32; i++)
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                if ((i & 3) == 0) traj[i >> 2] = v; else traj[i >> 2] |= v << (8 * (i & 3));
                 if (v < (uint32_t)MAXTOK) v = hf[ring_off(v) + 4u * (uint32_t)i];
+            }
             {
                 /* wave function = second half after first half */
                 const uint32_t second = (uint32_t)__shfl((int)v, 32 + (int)(v < (uint32_t)MAXTOK ? v : 0u));
@@ -1022,11 +1029,15 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
                 const uint32_t h1 = (uint32_t)__shfl((int)v, (int)(e < (uint32_t)MAXTOK ? e : 0u));
                 if ((l & 32) && e < (uint32_t)MAXTOK) e = h1;
             }
-            entry = e;
-#pragma unroll 4
-            for (int i = 0; i < 32; i++) {
-                if (k == i) entry = e;
-                if (e < (uint32_t)MAXTOK) e = hf[ring_off(e) + 4u * (uint32_t)i];
+            {
+                const int src = (l & 32) + (int)(e < (uint32_t)MAXTOK ? e : 0u); /* the lane that followed my half's entry */
+                uint32_t word = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t t = (uint32_t)__shfl((int)traj[j], src);
+                    word = (k >> 2) == j ? t : word;
+                }
+                entry = e < (uint32_t)MAXTOK ? (word >> (8 * (k & 3))) & 0xffu : e;
             }
         }
         widx++;
