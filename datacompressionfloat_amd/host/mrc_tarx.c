@@ -101,5 +101,8 @@ int main(int argc, char *argv[])
     free(th);
     free(args);
     free_file_container(&fnames);
+    /* every output file is closed; the process's death releases what the HIP runtime's destructors would release one by one
+     * (0.1 s of the command's wall time).  MRCZ_FULL_TEARDOWN=1 keeps the orderly way. */
+    if (!getenv("MRCZ_FULL_TEARDOWN")) { fflush(stdout); fflush(stderr); _exit(0); }
     return 0;
 }

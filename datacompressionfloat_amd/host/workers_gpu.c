@@ -37,6 +37,7 @@ int isTestThroughput = 0; /* src/core/workers.c:39 */
 #define R_IN 4                    /* pinned input ring: chunk-sized slots */
 #define R_OUT 6                   /* pinned output ring */
 #define OUT_SLOT (16u << 20)      /* bytes per output slice */
+#define MAXWRITERS 8
 #define NWRITERS 3                /* threads that pwrite() finished slices (a single thread writes ~5.5 GB/s into the page cache) */
 #define CHUNK_BYTES ((uint64_t)CHUNK_SIZE * 4u)
 #define IN_SLOT (CHUNK_BYTES + 64u) /* a chunk of floats, or a chunk record (16-byte header + <= 4 RAW planes) */
@@ -279,6 +280,83 @@ static void trace_report(const pipe_t *p, const char *what, double elapsed, uint
             p->t_slotwait, p->gpu_time, p->t_d2hwait, p->t_fwrite, (unsigned long long)p->nbatches, p->batch_chunks);
 }
 
+/* A chunk goes from the page cache (the input mapping) into a pinned ring slot with NFILL threads, each copying a third of
+ * it (one thread moves 6-8 GB/s out of the page cache, the host->device copy from pinned memory ~50 GB/s and asynchronous; a
+ * copy straight from the pageable mapping, which the runtime stages itself, moves ~8 GB/s and blocks the reader).
+ * MRCZ_FILLERS=0 keeps the direct copy from the mapping. */
+#define NFILL 3
+typedef struct {
+    pthread_t th[NFILL - 1];
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    uint64_t gen;          /* job number; helpers run job gen when it changes */
+    int pending;           /* helpers still copying the current job */
+    int quit;
+    unsigned char *dst;
+    const unsigned char *src;
+    uint64_t bytes;
+    int started;
+    int nthreads;          /* 1..NFILL copy threads, the caller included (MRCZ_FILLERS) */
+} fillpool_t;
+typedef struct { fillpool_t *fp; int part; } fillarg_t;
+static void fill_part(const fillpool_t *fp, int part)
+{
+    const uint64_t per = ((fp->bytes + (uint64_t)fp->nthreads - 1) / (uint64_t)fp->nthreads + 4095u) & ~(uint64_t)4095u;
+    const uint64_t a = per * (uint64_t)part, b = a + per < fp->bytes ? a + per : fp->bytes;
+    if (a < b) memcpy(fp->dst + a, fp->src + a, (size_t)(b - a));
+}
+static void *fill_main(void *arg)
+{
+    fillarg_t *fa = (fillarg_t *)arg;
+    fillpool_t *fp = fa->fp;
+    uint64_t seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&fp->mu);
+        while (fp->gen == seen && !fp->quit) pthread_cond_wait(&fp->cv, &fp->mu);
+        if (fp->quit) { pthread_mutex_unlock(&fp->mu); break; }
+        seen = fp->gen;
+        pthread_mutex_unlock(&fp->mu);
+        fill_part(fp, fa->part);
+        pthread_mutex_lock(&fp->mu);
+        if (--fp->pending == 0) pthread_cond_broadcast(&fp->cv);
+        pthread_mutex_unlock(&fp->mu);
+    }
+    return NULL;
+}
+static void fill_copy(fillpool_t *fp, fillarg_t *fa, unsigned char *dst, const unsigned char *src, uint64_t bytes)
+{
+    if (!fp->started) {
+        pthread_mutex_init(&fp->mu, NULL);
+        pthread_cond_init(&fp->cv, NULL);
+        for (int i = 0; i < fp->nthreads - 1; i++) {
+            fa[i].fp = fp; fa[i].part = i + 1;
+            if (pthread_create(&fp->th[i], NULL, fill_main, &fa[i]) != 0) die("pthread_create", NULL);
+        }
+        fp->started = 1;
+    }
+    pthread_mutex_lock(&fp->mu);
+    fp->dst = dst; fp->src = src; fp->bytes = bytes;
+    fp->pending = fp->nthreads - 1;
+    fp->gen++;
+    pthread_cond_broadcast(&fp->cv);
+    pthread_mutex_unlock(&fp->mu);
+    fill_part(fp, 0);
+    pthread_mutex_lock(&fp->mu);
+    while (fp->pending) pthread_cond_wait(&fp->cv, &fp->mu);
+    pthread_mutex_unlock(&fp->mu);
+}
+static void fill_stop(fillpool_t *fp)
+{
+    if (!fp->started) return;
+    pthread_mutex_lock(&fp->mu);
+    fp->quit = 1;
+    pthread_cond_broadcast(&fp->cv);
+    pthread_mutex_unlock(&fp->mu);
+    for (int i = 0; i < fp->nthreads - 1; i++) pthread_join(fp->th[i], NULL);
+    pthread_mutex_destroy(&fp->mu);
+    pthread_cond_destroy(&fp->cv);
+}
+
 /* The input file as one read-only mapping, if it can be mapped (a regular file): its pages go from the page cache to the
  * device with no copy into a staging buffer in between (fread into pinned memory moves ~6-8 GB/s per thread; the
  * host->device copy straight from the mapping ~18 GB/s on first touch).  NULL = use the fread ring. */
@@ -304,6 +382,12 @@ static void *reader_main(void *arg)
     uint64_t chunk = 0, k = 0, done_floats = 0;
     uint64_t mpos = 0, msize = 0;
     const unsigned char *map = map_input(p->fin, &mpos, &msize);
+    const int fillers = map && !(getenv("MRCZ_FILLERS") && atoi(getenv("MRCZ_FILLERS")) == 0); /* mapping -> pinned ring -> device */
+    fillpool_t fp;
+    fillarg_t fa[NFILL - 1];
+    memset(&fp, 0, sizeof(fp));
+    fp.nthreads = NFILL;
+    if (getenv("MRCZ_FILLERS")) { const int v = atoi(getenv("MRCZ_FILLERS")); if (v >= 1 && v <= NFILL) fp.nthreads = v; }
     int eof = 0;
     while (!eof) {
         const int di = (int)(k % nd), b = (int)((k / nd) & 1u), qi = 2 * di + b;
@@ -327,7 +411,7 @@ static void *reader_main(void *arg)
             unsigned char *ring = NULL;
             int slot = 0;
             double tt = now_sec();
-            if (!map) {
+            if (!map || fillers) {
                 slot = (int)(chunk % R_IN);
                 if (chunk >= R_IN) { /* the slot's previous upload (possibly to another device) is done */
                     devses_t *P = &s->d[s->in_dev[slot]];
@@ -345,6 +429,7 @@ static void *reader_main(void *arg)
                 if (map) {
                     if (mpos + bytes > msize) die("input file shrank while it was read", NULL);
                     h = map + mpos;
+                    if (fillers) { fill_copy(&fp, fa, ring, h, bytes); h = ring; }
                 } else {
                     if (fread(ring, sizeof(uint32_t), (size_t)nfl, p->fin) != nfl) die("input file shrank while it was read", NULL);
                     h = ring;
@@ -367,6 +452,7 @@ static void *reader_main(void *arg)
                 if (map) {
                     if (mpos + bytes > msize) die("truncated container (payload)", NULL);
                     h = map + mpos;
+                    if (fillers) { fill_copy(&fp, fa, ring, h, bytes); h = ring; }
                 } else {
                     memcpy(ring, hd16, 16);
                     if (fread(ring + 16, 1, (size_t)pay, p->fin) != pay) die("truncated container (payload)", NULL);
@@ -378,9 +464,9 @@ static void *reader_main(void *arg)
             done_floats += nfl;
             mpos += bytes;
             if (done_floats >= p->total_floats) eof = 1;
-            if (!map) p->t_fread += now_sec() - tt;
+            if (!map || fillers) p->t_fread += now_sec() - tt;
             CK(mrcz_copy_h2d_async(c, MRCZ_STREAM_UPLOAD, (char *)D->d_a[b] + off, h, bytes), "H2D copy", c);
-            if (map) p->t_fread += now_sec() - tt; /* a copy from pageable memory returns when the source has been consumed */
+            if (map && !fillers) p->t_fread += now_sec() - tt; /* a copy from pageable memory returns when the source has been consumed */
             else { CK(mrcz_event_record(c, MRCZ_STREAM_UPLOAD, D->in_ev[slot]), "event record", c); s->in_dev[slot] = di; }
             off += bytes;
             chunk++;
@@ -396,6 +482,7 @@ static void *reader_main(void *arg)
         pthread_mutex_unlock(&p->mu);
         k++;
     }
+    fill_stop(&fp);
     if (map) {
         /* the mapping may only go away once every copy out of it is done (a copy from pageable memory is normally complete when
          * the call returns; the event makes it certain) */
@@ -451,12 +538,14 @@ static void *writer_main(void *arg)
     session_t *s = p->s;
     const uint64_t nd = (uint64_t)p->nd;
     uint64_t oslice = 0; /* output ring position */
-    pthread_t pw[NWRITERS];
+    pthread_t pw[MAXWRITERS];
+    int nwr = NWRITERS;
+    if (getenv("MRCZ_WRITERS")) { const int v = atoi(getenv("MRCZ_WRITERS")); if (v >= 1 && v <= MAXWRITERS) nwr = v; }
     const int par = p->fd_out >= 0 && isTestThroughput != 1;
     if (par) {
         pthread_mutex_init(&p->wmu, NULL);
         pthread_cond_init(&p->wcv, NULL);
-        for (int i = 0; i < NWRITERS; i++)
+        for (int i = 0; i < nwr; i++)
             if (pthread_create(&pw[i], NULL, pwrite_main, p) != 0) die("pthread_create", NULL);
     }
     for (uint64_t k = 0;; k++) {
@@ -544,7 +633,7 @@ static void *writer_main(void *arg)
         p->wq_done = 1;
         pthread_cond_broadcast(&p->wcv);
         pthread_mutex_unlock(&p->wmu);
-        for (int i = 0; i < NWRITERS; i++) pthread_join(pw[i], NULL);
+        for (int i = 0; i < nwr; i++) pthread_join(pw[i], NULL);
         pthread_mutex_destroy(&p->wmu);
         pthread_cond_destroy(&p->wcv);
     }
