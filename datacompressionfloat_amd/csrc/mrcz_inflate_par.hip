@@ -93,6 +93,7 @@ struct ParShared {
     uint8_t wtot[PT / 64][32];     /* exit function of each wave's 64 pieces, one byte per entry offset */
     uint32_t scan_a[PT / 64];
     uint32_t scan_b[PT / 64];
+    uint32_t scan_c[PT / 64], scan_d[PT / 64], scan_e[PT / 64];
     HuffAux lit;
     uint32_t tok[1 << LBITS];
     HuffDecD dist;
@@ -611,6 +612,48 @@ __device__ __forceinline__ uint32_t block_min_pt(uint32_t v, uint32_t *wtot)
     return r;
 }
 
+/* Everything a window needs from the lanes' count walks, with ONE workgroup barrier (five separate scans cost ten): the
+ * exclusive prefix sum of the bytes produced and their total, the last literal decoded by a lane before this one, the
+ * first lane that ended the block or failed, the failure kinds seen, the first lane that decoded a literal. */
+struct WinScan { uint32_t myoff, total, before, stop_tid, bad, firstlit_tid; };
+__device__ __forceinline__ WinScan window_scan(ParShared &sh, int tid, uint32_t nout, uint32_t lastlit, uint32_t flags)
+{
+    const int l = lane_id(), w = tid >> 6;
+    uint32_t x = nout, ll = lastlit;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d), z = __shfl_up(ll, d);
+        if (l >= d) { x += y; if (!ll) ll = z; }
+    }
+    const unsigned long long bstop = __ballot((flags & (F_EOB | F_ERR)) != 0u);
+    const unsigned long long bgen = __ballot((flags & F_GENERAL) != 0u), berr = __ballot((flags & F_ERR) != 0u);
+    const unsigned long long blit = __ballot(lastlit != 0u);
+    if (l == 63) { sh.scan_a[w] = x; sh.scan_b[w] = ll; }
+    if (l == 0) {
+        sh.scan_c[w] = bstop ? (uint32_t)(64 * w + ctz64(bstop)) : 0xffffffffu;
+        sh.scan_d[w] = (bgen ? (uint32_t)F_GENERAL : 0u) | (berr ? (uint32_t)F_ERR : 0u);
+        sh.scan_e[w] = blit ? (uint32_t)(64 * w + ctz64(blit)) : 0xffffffffu;
+    }
+    uint32_t e1 = __shfl_up(ll, 1);
+    if (l == 0) e1 = 0;
+    __syncthreads();
+    WinScan r;
+    uint32_t pre = 0, tot = 0, prelast = 0;
+    r.stop_tid = 0xffffffffu; r.firstlit_tid = 0xffffffffu; r.bad = 0;
+#pragma unroll
+    for (int i = 0; i < PT / 64; i++) {
+        const uint32_t t = sh.scan_a[i], tl = sh.scan_b[i], tc = sh.scan_c[i], te = sh.scan_e[i];
+        if (i < w) { pre += t; if (tl) prelast = tl; }
+        tot += t;
+        r.stop_tid = tc < r.stop_tid ? tc : r.stop_tid;
+        r.firstlit_tid = te < r.firstlit_tid ? te : r.firstlit_tid;
+        r.bad |= sh.scan_d[i];
+    }
+    r.myoff = pre + x - nout;
+    r.total = tot;
+    r.before = e1 ? e1 : prelast;
+    return r;
+}
+
 /* stage `nwords` dwords of the payload starting at the dword that holds payload bit `bit` */
 __device__ __forceinline__ uint32_t stage_bits(uint32_t *dst, int nwords, const uint8_t *rec, uint64_t reclen,
                                                uint64_t paybit0, uint32_t bit)
@@ -1049,18 +1092,15 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         if (start != POS_INVALID) r = dbl ? count_walk<true, false, true>(sh, start, limit) : count_walk<true>(sh, start, limit);
         else { r.land = POS_INVALID; r.nout = 0; r.flags = 0; r.lastlit = 0; } /* behind END_BLOCK or behind a token the walk of an earlier lane flags */
         PHASE(4);
-        /* first lane that ended the block (or failed); lanes after it are inactive */
-        const uint32_t e = block_min_pt((r.flags & (F_EOB | F_ERR)) ? (uint32_t)tid : 0xffffffffu, sh.scan_a);
         const bool active = start != POS_INVALID;
-        if (tid == 0) sh.flag = 0;
-        __syncthreads();
-        if (r.flags & (F_GENERAL | F_ERR)) sh.flag = r.flags | F_ERR;
-        __syncthreads();
-        const uint32_t bad_flags = sh.flag;
-        uint32_t total;
-        const uint32_t myoff = block_excl_sum_pt(active ? r.nout : 0u, sh.scan_a, &total);
-        PHASE(5);
+        const uint32_t haslit0 = sh.haslit; /* (thread PT-1 rewrites them at the end of the window) */
+        const uint32_t lastin = sh.last;
         const uint32_t op = sh.op;
+        const WinScan ws = window_scan(sh, tid, active ? r.nout : 0u, active ? r.lastlit : 0u, r.flags);
+        const uint32_t e = ws.stop_tid; /* first lane that ended the block (or failed); lanes after it are inactive */
+        const uint32_t total = ws.total, myoff = ws.myoff, before = ws.before;
+        const uint32_t bad_flags = ws.bad ? (ws.bad | (uint32_t)F_ERR) : 0u;
+        PHASE(5);
         if (bad_flags || op + total > sv.n) {
             if (tid == 0) sh.status = (bad_flags & F_GENERAL) ? 3 : 2;
             __syncthreads();
@@ -1070,8 +1110,6 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
          * four to a store, distance-1 matches as fills of the last literal (wide aligned stores for long runs).
          * A lane's output range is contiguous, lanes are independent, nothing is staged. */
         uint8_t *wout;
-        const uint32_t haslit0 = sh.haslit; /* read before the scans' barriers: thread PT-1 rewrites it below */
-        const uint32_t lastin = sh.last;
         if (MODE == MODE_SCRATCH) {
             if (tid == 0) {
                 const uint32_t units = (total + 15u) >> 4;
@@ -1085,9 +1123,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
                 sh.wbase = b16;
                 sh.nwin = widx;
             }
-        }
-        const uint32_t before = block_excl_last_pt(active ? r.lastlit : 0u, sh.scan_b); /* contains barriers: sh.wbase is visible after it */
-        if (MODE == MODE_SCRATCH) {
+            __syncthreads(); /* sh.wbase */
             if (sh.wbase == 0xffffffffu) { /* more windows than a candidate records, or the scratch buffer is full */
                 if (tid == 0) sh.status = 2;
                 __syncthreads();
@@ -1096,9 +1132,8 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
             wout = so.base + (size_t)sh.wbase * 16u + myoff;
             if (!haslit0) {
                 /* the bytes in front of the block's first literal replicate the previous block's last byte, which is
-                 * not known here: remember how many there are, k_blk_gather fills them in */
-                const uint32_t fl = block_min_pt((active && r.lastlit) ? (uint32_t)tid : 0xffffffffu, sh.scan_a);
-                if ((uint32_t)tid == fl) sh.lead = op + myoff + (dbl ? count_walk<false, true, true>(sh, start, limit).nout : count_walk<false, true>(sh, start, limit).nout);
+                 * not known here: remember how many there are, the merge fills them in */
+                if ((uint32_t)tid == ws.firstlit_tid) sh.lead = op + myoff + (dbl ? count_walk<false, true, true>(sh, start, limit).nout : count_walk<false, true>(sh, start, limit).nout);
             }
         } else wout = sv.out + op + myoff;
         if (active && r.nout) {
@@ -1225,14 +1260,18 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t wnext = j < 3 ? wc[j < 3 ? j + 1 : 3] : stepw[4u * lane + 4u]; /* the next lane's (or step's) first dword */
-            const unsigned long long win = (unsigned long long)wc[j] | ((unsigned long long)wnext << 32);
             /* bit-parallel signature test of the 32 positions that start in this dword:
              *   bits 0..2 = 0,0,1 (BFINAL 0, BTYPE 2)   bits 8..12 = 1,0,0,0,0 (HDIST == 1)
              *   HLIT = bits 3..7 <= 29  <=>  not (bits 4,5,6,7 all set)
-             * Two positions less than 5 bits apart cannot both fit, so a dword queues at most 7. */
-            const unsigned long long sig = ~win & ~(win >> 1) & (win >> 2) & (win >> 8) & ~(win >> 9) & ~(win >> 10) & ~(win >> 11) &
-                                           ~(win >> 12) & ~((win >> 4) & (win >> 5) & (win >> 6) & (win >> 7));
-            uint32_t hits = (uint32_t)sig;
+             * Two positions less than 5 bits apart cannot both fit, so a dword queues at most 7.  Only the low 32 bits of each
+             * shifted window matter: one funnel shift (v_alignbit) per term instead of a 64-bit shift. */
+            const uint32_t lo = wc[j];
+#define SH(k) __builtin_amdgcn_alignbit(wnext, lo, (k))
+            const uint32_t must1 = SH(2) & SH(8);
+            const uint32_t must0 = lo | SH(1) | SH(9) | SH(10) | SH(11) | SH(12) | (SH(4) & SH(5) & SH(6) & SH(7));
+            const uint32_t sig = must1 & ~must0;
+#undef SH
+            uint32_t hits = sig;
             while (hits) {
                 const int b = __builtin_ctz(hits);
                 hits &= hits - 1u;

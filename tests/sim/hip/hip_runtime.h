@@ -164,4 +164,5 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return sim_exchange(v, lane & 63); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return sim_exchange(v, 0); }
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
 static inline int __builtin_amdgcn_writelane(int v, int lane, int old) { return sim_lane() == (lane & 63) ? v : old; }
