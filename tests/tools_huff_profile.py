@@ -19,7 +19,7 @@ for s in (0, 1):
     v += list(buf)
 names = ["load freqs + heap fill", "merge loop (lit/len)", "gen_bitlen", "overflow repair", "gen_codes + code rows", "scan_tree", "bit-length tree", "header bits + meta"]
 trees = max(v[32], 1)
-print(f"trees {v[32]}  (clock64 ticks, 100 MHz)")
+print(f"trees {v[32]}  (shader clocks per tree, thousands)")
 for i, nm in enumerate(names):
-    print(f"  {nm:28s} max {v[i] / 100.0:8.1f} us   mean {v[16 + i] / trees / 100.0:8.1f} us")
-print(f"  sum of max {sum(v[:8]) / 100.0:.1f} us, sum of mean {sum(v[16:24]) / trees / 100.0:.1f} us")
+    print(f"  {nm:28s} max {v[i] / 1000.0:8.1f} k   mean {v[16 + i] / trees / 1000.0:8.1f} k")
+print(f"  sum of max {sum(v[:8]) / 1000.0:.1f} k, sum of mean {sum(v[16:24]) / trees / 1000.0:.1f} k")

@@ -21,7 +21,7 @@ for s in ((4, 5, 6, 7) if MODE == 1 else (5, 6, 7)):
     _LIB.mrcz_debug_inflate_phases(c._ctx, MODE, s, buf)
     v = list(buf)
     tot = sum(v[:10]) + sum(v[12:20])
-    print(f"stream {s} (plane {s % 4}): blocks={v[10]} windows={v[11]} total={tot / 1e8:.2f} ms@100MHz " +
+    print(f"stream {s} (plane {s % 4}): blocks={v[10]} windows={v[11]} total={tot / 1e6:.1f} M shader clocks (thread 0 of every block, summed) " +
           " ".join(f"{names[i]}={100.0 * v[i] / max(tot, 1):.1f}%" for i in range(9)) + " | hdr: " + " ".join(f"{n}={100.0 * v[12 + i] / max(tot, 1):.1f}%" for i, n in enumerate(["first", "blcode", "lens-write+sync", "lit", "dist", "lens-exitfn", "lens-compose", "lens-count"])) + f" rest={100.0 * v[0] / max(tot, 1):.1f}%")
 
 cnt = (ctypes.c_uint64 * 2)()
