@@ -936,6 +936,9 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
     }
     if (sh.btype == 0) {
         /* stored block: copy LEN bytes (the block-parallel path sizes and copies stored blocks elsewhere) */
+        __syncthreads(); /* every thread is past the status test above before thread 0 may change the status again: a wave that
+                          * saw the new value there left through it, and the workgroup's waves disagreed on the number of barriers
+                          * from then on (found by the emulator on a plane that begins with a stored block) */
         if (MODE == MODE_SCRATCH) { if (tid == 0) sh.status = 2; __syncthreads(); return; }
         const uint32_t l = sh.nlen, op = sh.op;
         const uint32_t byte0 = sh.cur >> 3;

@@ -53,6 +53,7 @@ static inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r = {a, b}; retur
 void sim_launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem);
 void sim_block_barrier();
 void sim_wave_barrier();
+void sim_set_site(int line);
 extern unsigned char *sim_dynamic_shared;
 uint64_t *sim_wave_slots(); /* 64 slots for the current wave */
 int sim_lane();
@@ -61,7 +62,8 @@ int sim_lane();
     sim_launch([=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (size_t)(shmem))
 #define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)sim_dynamic_shared;
 
-static inline void __syncthreads() { sim_block_barrier(); }
+static inline void sim_syncthreads_at(int line) { sim_set_site(line); sim_block_barrier(); }
+#define __syncthreads() sim_syncthreads_at(__LINE__)
 
 template <typename T> static inline uint64_t sim_to_bits(T v) { uint64_t b = 0; memcpy(&b, &v, sizeof(T)); return b; }
 template <typename T> static inline T sim_from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
@@ -157,7 +159,8 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) {
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e3); return hipSuccess; }
-static inline void __builtin_amdgcn_wave_barrier() { sim_wave_barrier(); }
+static inline void sim_wave_barrier_at(int line) { sim_set_site(line); sim_wave_barrier(); }
+#define __builtin_amdgcn_wave_barrier() sim_wave_barrier_at(__LINE__)
 static inline long long clock64() { return 0; }
 #define __noinline__ __attribute__((noinline))
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };

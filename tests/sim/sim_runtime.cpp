@@ -38,6 +38,8 @@ struct Fiber {
 #endif
     int state;
     unsigned tid;
+    int site; /* source line of the barrier / cross-lane operation the fiber waits in (deadlock report) */
+    int hist[8]; /* the sites before it, newest first */
 };
 const size_t kStack = 256 * 1024;
 std::vector<Fiber> fibers;
@@ -111,6 +113,13 @@ void yield_as(int st)
 }
 }  // namespace
 
+void sim_set_site(int line)
+{
+    Fiber &f = fibers[cur];
+    for (int i = 7; i > 0; i--) f.hist[i] = f.hist[i - 1];
+    f.hist[0] = f.site;
+    f.site = line;
+}
 void sim_block_barrier() { yield_as(WAIT_BLOCK); }
 void sim_wave_barrier() { yield_as(WAIT_WAVE); }
 uint64_t *sim_wave_slots() { return wave_slots[fibers[cur].tid / 64]; }
@@ -177,6 +186,10 @@ void sim_launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t
                             if (fibers[t].state == WAIT_BLOCK) fibers[t].state = RUN;
                         continue;
                     }
+                    for (unsigned t = 0; t < nthreads; t++) /* where the minority waits: the divergent path */
+                        if (fibers[t].state != DONE && (t % 64 == 0 || fibers[t].site != fibers[t - 1].site || fibers[t].state != fibers[t - 1].state))
+                            fprintf(stderr, "sim:   thread %u.. waits at %s, source line %d (before: %d %d %d %d %d %d)\n", t, fibers[t].state == WAIT_BLOCK ? "the block barrier" : "a wave barrier / cross-lane operation", fibers[t].site,
+                                    fibers[t].hist[0], fibers[t].hist[1], fibers[t].hist[2], fibers[t].hist[3], fibers[t].hist[4], fibers[t].hist[5]);
                     fprintf(stderr, "sim: deadlock in block (%u,%u,%u): %u live, %u at block barrier, rest at wave barriers\n",
                             bx, by, bz, live, waiting);
                     abort();

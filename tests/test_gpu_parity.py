@@ -132,6 +132,14 @@ def test_skewed_alphabets_force_length_overflow(codec, oracle):
     _roundtrip(codec, oracle, np.tile(w, 5), 0)
 
 
+def test_planes_that_begin_with_stored_blocks(codec, oracle):
+    # noise, then constants: the stream of every plane starts with STORED blocks and goes on with coded ones (see tests/test_sim.py)
+    rng = np.random.default_rng(11)
+    w = np.concatenate([rng.integers(0, 2**32, 300000, dtype=np.uint64).astype(np.uint32), np.full(400000, 0x41200000, np.uint32)])
+    _roundtrip(codec, oracle, w, 0)
+    assert codec.last_fallbacks() == 0
+
+
 def test_chunk_boundaries(codec, oracle):
     C = util.CHUNK
     for n in (C - 1, C, C + 1, 2 * C + 12345):

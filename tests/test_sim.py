@@ -52,6 +52,16 @@ def test_skewed_alphabets_force_length_overflow(simlib, oracle):
     _check(simlib, oracle, np.tile(w, 2), 0)
 
 
+def test_planes_that_begin_with_stored_blocks(simlib, oracle):
+    # noise, then constants: every plane's stream starts with a STORED block and goes on with coded ones, so the candidate at
+    # bit 0 is a stored block (this is the input on which the emulator caught waves of the block decoder disagreeing on the
+    # number of barriers: thread 0 changed sh.status while slower waves were still testing it)
+    rng = np.random.default_rng(11)
+    for nn, nz in ((34000, 40000), (70000, 70000)):
+        w = np.concatenate([rng.integers(0, 2**32, nn, dtype=np.uint64).astype(np.uint32), np.full(nz, 0x41200000, np.uint32)])
+        _check(simlib, oracle, w, 0)
+
+
 def test_kat_a(simlib, oracle):
     w = util.kat_words(300000)
     for b in (0, 23):

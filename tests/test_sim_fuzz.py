@@ -15,25 +15,60 @@ import util
 lib = ctypes.CDLL(os.environ["SIM_ASAN"])
 sim = util.SimCodec(lib)
 rng = np.random.default_rng(11)
-words = util.gauss_words(60000, seed=3)
+words = util.gauss_words(36000, seed=3)
 good = sim.compress_records(words, 8)
 assert np.array_equal(sim.uncompress_records(good, len(words)), util.erase_expected(words, 8))
+# a second container whose streams hold STORED blocks in front of coded ones (noise, then constants, in every plane)
+mixed = np.concatenate([rng.integers(0, 2**32, 34000, dtype=np.uint64).astype(np.uint32), np.full(40000, 0x41200000, np.uint32)])
+good2 = sim.compress_records(mixed, 0)
+assert np.array_equal(sim.uncompress_records(good2, len(mixed)), mixed)
 # the compressor and the decoder on ragged sizes, under the sanitizer as well
 for n in (1, 257, 4097):
     w = util.poisson_words(n, seed=n)
     assert np.array_equal(sim.uncompress_records(sim.compress_records(w, 12), n), util.erase_expected(w, 12))
 decoded = rejected = 0
-for it in range(int(os.environ["CASES"])):
-    b = bytearray(good)
-    for _ in range(int(rng.integers(1, 6))):
-        b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
-    if it % 5 == 4:
-        b = b[: int(rng.integers(16, len(b)))]          # truncation
+def attempt(b, n):
+    global decoded, rejected
     try:
-        sim.uncompress_records(bytes(b), len(words))
+        sim.uncompress_records(bytes(b), n)
         decoded += 1
     except RuntimeError:
         rejected += 1
+def payload_offsets(rec):
+    lens = [int.from_bytes(rec[4 * j:4 * j + 4], "little") & 0x7fffffff for j in range(4)]
+    offs, o = [], 16
+    for l in lens:
+        offs.append(o); o += l
+    return offs, lens
+cases = int(os.environ["CASES"])
+for it in range(cases):
+    src, n = (good, len(words)) if it % 2 == 0 else (good2, len(mixed))
+    b = bytearray(src)
+    kind = it % 6
+    offs, lens = payload_offsets(src)
+    if kind == 0:                                   # random bit flips anywhere
+        for _ in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:                                 # the 16-byte chunk header: payload lengths and RAW flags
+        j = int(rng.integers(0, 16))
+        b[j] = int(rng.integers(0, 256))
+        if it % 12 == 1: b[4 * int(rng.integers(0, 4)) + 3] = 0x7f   # a length of ~2 GiB
+    elif kind == 2:                                 # the first block header of a stream: BTYPE, HLIT, HDIST, HCLEN, code-length code
+        k = int(rng.integers(0, 4))
+        for _ in range(int(rng.integers(1, 4))):
+            b[offs[k] + int(rng.integers(0, min(12, max(lens[k], 1))))] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 3:                                 # LEN / NLEN of a stored block (streams of good2 start with one), or the bytes in their place
+        k = int(rng.integers(0, 4))
+        j = offs[k] + 1 + int(rng.integers(0, 4))
+        if j < len(b): b[j] = int(rng.integers(0, 256))
+    elif kind == 4:                                 # truncation
+        b = b[: int(rng.integers(16, len(b)))]
+    else:                                           # a burst of garbage inside one payload
+        k = int(rng.integers(0, 4))
+        if lens[k] > 64:
+            at = offs[k] + int(rng.integers(0, lens[k] - 32))
+            b[at:at + 32] = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    attempt(b, n)
 print("FUZZ-OK", decoded, rejected)
 '''
 
@@ -50,7 +85,7 @@ def test_corrupted_containers_never_touch_foreign_memory(tmp_path):
                            os.path.join(csrc, "mrcz_api.hip"), os.path.join(util.SIM_DIR, "sim_runtime.cpp")])
     script = tmp_path / "fuzz.py"
     script.write_text(SCRIPT)
-    env = dict(os.environ, REPO=util.ROOT, SIM_ASAN=str(so), CASES="15", LD_PRELOAD=asan_rt,
+    env = dict(os.environ, REPO=util.ROOT, SIM_ASAN=str(so), CASES="24", LD_PRELOAD=asan_rt,
                ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1")
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
     assert r.returncode == 0 and "FUZZ-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
