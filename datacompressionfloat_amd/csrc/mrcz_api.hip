@@ -143,13 +143,7 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->lanes = 2;
     if (const char *ev = getenv("MRCZ_LANES")) { const int v = atoi(ev); if (v >= 1 && v <= MAX_LANES) ctx->lanes = (uint32_t)v; }
     if (max_batch_chunks < 8u) ctx->lanes = 1; /* batches under 8 chunks run as one lane anyway */
-    {   /* MRCZ_PRIO (experiments): bit l set = lane l's stream is created with the highest priority */
-        int prio_mask = 0, plo = 0, phi = 0;
-        if (const char *ev = getenv("MRCZ_PRIO")) prio_mask = atoi(ev);
-        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-        for (uint32_t l = 1; l < ctx->lanes && e == hipSuccess; l++)
-            e = ((prio_mask >> l) & 1) ? hipStreamCreateWithPriority(&ctx->lane_stream[l], hipStreamDefault, phi) : hipStreamCreate(&ctx->lane_stream[l]);
-    }
+    for (uint32_t l = 1; l < ctx->lanes && e == hipSuccess; l++) e = hipStreamCreate(&ctx->lane_stream[l]); /* (stream priorities were tried: no effect on the lanes' overlap) */
     {   /* the block decoder runs as a fixed grid of three workgroups per CU (its LDS footprint admits exactly three) */
         hipDeviceProp_t prop;
         ctx->blk_grid = 768;

@@ -62,10 +62,6 @@ elif which == "split":
     for lanes in (3, 4):
         res.append(run({"MRCZ_LANES": lanes, "MRCZ_STAGGER": 1}))
         print(json.dumps(res[-1]), flush=True)
-elif which == "prio":
-    for lanes, stagger, prio in [(2, 0, 0), (2, 1, 0), (2, 1, 2), (2, 0, 2), (3, 1, 0), (3, 1, 6), (3, 1, 4), (3, 0, 0), (2, 1, 0), (2, 0, 0)]:
-        res.append(run({"MRCZ_LANES": lanes, "MRCZ_STAGGER": stagger, "MRCZ_PRIO": prio}))
-        print(json.dumps(res[-1]), flush=True)
 elif which == "hint":
     for h in (1, 0, 1, 0):
         res.append(run({"MRCZ_HINT": h}))
