@@ -7,24 +7,27 @@
  *   k_scan_candidates      every bit position of every payload is tested for the fixed fields of a dynamic block
  *                          header as Z_RLE streams carry them, survivors for a complete code-length code;
  *   k_validate_candidates  one lane per survivor parses the whole header; the decoded code lengths are kept;
- *   k_blk_count            one 512-thread workgroup per candidate decodes the block as if it were real, leaves its
- *                          bytes in a scratch buffer and records where it ends and what it produced;
+ *   k_blk_count            a fixed grid of 512-thread workgroups pulls candidates from a device counter; each decodes
+ *                          its block as if it were real, leaves the bytes in a scratch buffer (one piece per window)
+ *                          and records where the block ends and what it produced;
  *   k_chain                per stream, keeps the candidates that start exactly where the previous block ended
- *                          (stored blocks are sized on the spot) and assigns plane offsets;
- *   k_blk_gather           moves the accepted blocks from scratch to their place in the plane;
+ *                          (stored blocks are sized on the spot) and lists the accepted blocks' windows as segments;
+ *   k_merge_segments       re-interleaves the four planes of every tile straight from their segments (no copy of the
+ *                          decoded blocks into a plane buffer in between);
  *   k_inflate_par          fallback: walks a stream's blocks one after the other with the same per-block code
  *                          (streams whose chain did not close: static blocks, foreign encoders, ...).
  * Correctness never depends on the speculation: a block is only used if the chain from bit 0 reaches it.
  *
  * Inside a block (decode_one_block) the symbols are decoded in parallel.  Prefix codes of near-uniform byte planes
  * are almost fixed-length and do NOT self-synchronise, so the parse is resolved exactly, window by window
- * (512 x 256 bits staged in LDS, one 256-bit piece per lane):
+ * (512 pieces staged in LDS, one per lane; 256 bits each, fewer when the block is known to end inside the window):
  *   P1  every lane runs the backward recurrence exit[k] = exit[k + bits(token at k)] over all bit positions of its
  *       piece (exit values in a lane-private LDS ring): for a token starting e bits into the piece (e < 24), how many
- *       bits into the next piece the token chain lands (31 = chain hit END_BLOCK, 30 = invalid / unsupported token);
- *   P2  the pieces' entry offsets follow by chained table walks inside each wave and a fold over the wave totals;
- *   P3  lanes walk their piece from the true entry counting plane bytes; workgroup scans yield output offsets and
- *       the byte a distance-1 match replicates;
+ *       bits into the next piece the token chain lands (28 = the chain stops: END_BLOCK, or a token this path does not follow);
+ *   P2  the pieces' entry offsets: every wave walks its 64 exit functions as a chain (and keeps the trajectories), the
+ *       waves' functions are folded, and each lane reads its entry off the trajectory of the true wave entry;
+ *   P3  lanes walk their piece from the true entry counting plane bytes; one workgroup scan yields output offsets, the
+ *       byte a distance-1 match replicates and the lane that ended the block;
  *   P4  lanes walk once more and write plane bytes (packed dword stores, wide stores for long runs).
  * Streams written by this codec (and by zlib Z_RLE) only contain distance-1 matches and tokens of at most 15+5+1
  * bits; a stream with other distances or tokens longer than 24 bits is handed to the sequential decoder in
