@@ -391,7 +391,7 @@ static int compress_enqueue(mrcz_ctx_t *ctx, const void *d_in, uint64_t nfloats,
     HIPCHK(hipEventRecord(ctx->ev_start, ctx->stream), "event");
     for (uint32_t l = 1; l < ctx->lanes; l++) HIPCHK(hipStreamWaitEvent(ctx->lane_stream[l], ctx->ev_start, 0), "wait");
     /* A batch runs as ctx->lanes lanes (contiguous parts of its chunks), one stream each: the Huffman kernel is
-     * one tree's latency long (0.9 ms whatever the number of trees) and leaves most of the machine idle, so the other
+     * one tree's latency long (0.6 ms whatever the number of trees) and leaves most of the machine idle, so the other
      * lanes' streaming passes and emit kernels run under it, and the lanes' Huffman kernels under each other.  Only
      * the layout step is ordered across lanes (running byte offset), through an event chain.  With per-kernel timing
      * on everything stays on one stream. */
