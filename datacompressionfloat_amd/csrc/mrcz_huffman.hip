@@ -115,19 +115,50 @@ template <int HT> __device__ __forceinline__ void sift_root(HeapTop &t, uint32_t
         if (stop) return;
         a = 2 * a + (right ? 1 : 0);
     }
-    /* level 3: node a in 8..15 (a register), children 16..31 in LDS; deeper levels as in sift_lds */
-    int o = 2 * a * HT;
+    /* From here on the nodes are in LDS, and what a level costs is the round trip for its two children.  So every round trip
+     * also fetches the four grandchildren (their slots follow from the node alone): two levels per wait.  Slots without a
+     * node hold values above every key, the last slot of the array always does and stands in for grandchildren beyond it. */
+    constexpr int INF_SLOT = (HSLOTS - 1) * HT;
+    int oc = 2 * a * HT; /* left child of register node a: nodes 16..31, their children 32..63 */
     {
-        const uint32_t c0 = hp[o], c1 = hp[o + HT];
+        const uint32_t c0 = hp[oc], c1 = hp[oc + HT];
+        const uint32_t g00 = hp[2 * oc], g01 = hp[2 * oc + HT], g10 = hp[2 * oc + 2 * HT], g11 = hp[2 * oc + 3 * HT];
         const bool right = c1 <= (c0 | 1023u);
         cj = right ? c1 : c0;
         const bool stop = v <= (cj | 1023u);
         const uint32_t put = stop ? v : cj;
         TOP_WRITE(t, 8, a, put);
         if (stop) return;
-        o = right ? o + HT : o;
+        int o = right ? oc + HT : oc;
+        const uint32_t gl = right ? g10 : g00, gr = right ? g11 : g01;
+        const bool right2 = gr <= (gl | 1023u);
+        cj = right2 ? gr : gl;
+        if (v <= (cj | 1023u)) { hp[o] = v; return; }
+        hp[o] = cj;
+        oc = 2 * o + (right2 ? HT : 0);
     }
-    sift_lds<HT>(hp, o, v);
+    int o = oc;
+    for (;;) {
+        const int aj = o << 1;
+        if (aj > (HSLOTS - 2) * HT) break; /* node o has no slots for children */
+        const bool has_g = 2 * aj + 3 * HT <= INF_SLOT;
+        const int gj = has_g ? 2 * aj : INF_SLOT;
+        const int gs = has_g ? HT : 0;
+        const uint32_t c0 = hp[aj], c1 = hp[aj + HT];
+        const uint32_t g00 = hp[gj], g01 = hp[gj + gs], g10 = hp[gj + 2 * gs], g11 = hp[gj + 3 * gs];
+        const bool right = c1 <= (c0 | 1023u);
+        cj = right ? c1 : c0;
+        if (v <= (cj | 1023u)) break;
+        hp[o] = cj;
+        o = right ? aj + HT : aj;
+        const uint32_t gl = right ? g10 : g00, gr = right ? g11 : g01;
+        const bool right2 = gr <= (gl | 1023u);
+        cj = right2 ? gr : gl;
+        if (v <= (cj | 1023u)) break;
+        hp[o] = cj;
+        o = 2 * o + (right2 ? HT : 0);
+    }
+    hp[o] = v;
 }
 
 /* heap holds n0 leaf keys (1-based).  Runs zlib's merge loop; returns the number of merges.  Merge i removes
@@ -138,6 +169,7 @@ template <int HT> __device__ __forceinline__ int merge_loop(uint32_t *heap, int 
     {   /* slots a walk can look at behind the end of the heap */
         const int last = 2 * n0 + 1 < HSLOTS ? 2 * n0 + 1 : HSLOTS - 1;
         for (int k = n0 + 1; k <= last; k++) hp[k * HT] = KEY_INF;
+        hp[(HSLOTS - 1) * HT] = KEY_INF; /* (sift_root reads it in place of grandchildren that have no slots) */
     }
     for (int k = n0 / 2; k >= 1; k--) sift_lds<HT>(hp, k * HT, hp[k * HT]);
     HeapTop t;
