@@ -48,7 +48,12 @@ constexpr int MAXTOK = 24;                    /* longest token (bits) the parall
  * while the group of k is processed (piece_exit_word). */
 constexpr uint32_t X_STOP = 28u;
 constexpr uint32_t X_ERR = X_STOP, X_EOB = X_STOP;
-constexpr int WIN_WORDS = WINBITS / 32 + 8;   /* + alignment lead + lookahead */
+/* A window's words are kept with one word of padding after every 64: lane t works on words t * nw .. (nw = 8, 4, 2 dwords
+ * per piece are the common cases), and without the skew the lanes of a wave would hit 8, 4 or 2 LDS banks only (counters:
+ * half of the kernel's LDS cycles were bank-conflict replays).  WSK maps a word index of the window to its place; the
+ * header staging (HDR_WORDS words at the front of the same buffer, at another time) is not skewed. */
+#define WSK(i) ((i) + ((i) >> 6))
+constexpr int WIN_WORDS = WINBITS / 32 + 8 + (WINBITS / 32 + 8) / 64 + 1;   /* + alignment lead + lookahead + skew padding */
 constexpr int HDR_WORDS = 192;                /* staged bits for a dynamic header */
 constexpr int LBITS = 12;                     /* index bits of the literal/length fast tables */
 constexpr int DBITS = 10;                     /* index bits of the distance fast table */
@@ -93,14 +98,16 @@ struct ParShared {
     uint32_t ring[8][PT];          /* per-piece exit values: byte (k & 3) of ring[(k >> 2) & 7][piece] = exit of position k of that
                                     * piece (k mod 32: a token is at most 24 bits); after P1 bytes 0..23 are the piece's exit function.
                                     * A piece's dwords all sit in LDS bank (piece mod 32): its own gathers never conflict. */
-    uint8_t wtot[PT / 64][32];     /* exit function of each wave's 64 pieces, one byte per entry offset */
+    union {                        /* (never alive together: the header of a block is parsed before its first window) */
+        uint8_t wtot[PT / 64][32]; /* exit function of each wave's 64 pieces, one byte per entry offset */
+        uint16_t bllut[128];       /* code-length code (<= 7 bits): sym | len << 9 */
+    };
     uint32_t scan_a[PT / 64];
     uint32_t scan_b[PT / 64];
     uint32_t scan_c[PT / 64], scan_d[PT / 64], scan_e[PT / 64];
     HuffAux lit;
     uint32_t tok[1 << LBITS];
     HuffDecD dist;
-    uint16_t bllut[128];      /* code-length code (<= 7 bits): sym | len << 9 */
     uint8_t bl[32];           /* code-length code lengths */
     uint32_t ncode, hpos;
     uint8_t lens[320];
@@ -314,8 +321,9 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
 {
     /* the window is staged dword-aligned, its first token starts `lead` (< 32) bits in: funnel the piece's dwords
      * once per 32 positions so that every bit offset below is a compile-time constant */
-    const uint32_t *wp = sh.win + tid * nw + (uint32_t)wq;
-    const unsigned long long a01 = ((unsigned long long)wp[1] << 32) | wp[0], a12 = ((unsigned long long)wp[2] << 32) | wp[1];
+    const uint32_t wi0 = tid * nw + (uint32_t)wq;
+    const uint32_t wp0 = sh.win[WSK(wi0)], wp1 = sh.win[WSK(wi0 + 1u)], wp2 = sh.win[WSK(wi0 + 2u)];
+    const unsigned long long a01 = ((unsigned long long)wp1 << 32) | wp0, a12 = ((unsigned long long)wp2 << 32) | wp1;
     const unsigned long long w01 = ((a12 >> lead) << 32) | (uint32_t)(a01 >> lead);
     const unsigned long long w01x4 = w01 << 2; /* index bits pre-scaled to the byte offset of a 4-byte table entry */
     const uint32_t kbase = 32u * (uint32_t)wq;
@@ -405,11 +413,11 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
     r.nout = 0; r.flags = 0; r.lastlit = 0;
     uint32_t pos = start;
     uint32_t wi = pos >> 5;
-    uint64_t buf = ((uint64_t)sh.win[wi] | ((uint64_t)sh.win[wi + 1] << 32)) >> (pos & 31u);
+    uint64_t buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
     int nb = 64 - (int)(pos & 31u);
     wi += 2;
     while (pos < limit) {
-        if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
+        if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
         const uint32_t idx = (uint32_t)buf & ((1u << LBITS) - 1u);
         const uint32_t e = sh.tok[idx];
         const uint32_t t = e & 0xffu;
@@ -453,7 +461,7 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
             const int xb = len_extra_bits(lc);
             const uint32_t ml = base_len_of(lc) + ((uint32_t)buf & ((1u << xb) - 1u));
             buf >>= xb; nb -= xb; pos += (uint32_t)xb;
-            if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
+            if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
             /* what the exit functions (token_bits) call unresolvable must be flagged by the lane that walks into it: the pieces
              * behind it only know that the chain stopped */
             if (!sh.dist.lut[(uint32_t)buf & ((1u << DBITS) - 1u)]) { r.flags |= F_ERR; break; } /* distance code beyond the fast table */
@@ -485,7 +493,7 @@ __device__ __noinline__ uint32_t walk_general_token(const ParShared &sh, uint32_
 {
     auto peek = [&](uint32_t p) -> uint32_t { /* >= 32 bits from window bit p */
         const uint32_t i = p >> 5;
-        return (uint32_t)((((unsigned long long)sh.win[i + 1] << 32) | sh.win[i]) >> (p & 31u));
+        return (uint32_t)((((unsigned long long)sh.win[WSK(i + 1u)] << 32) | sh.win[WSK(i)]) >> (p & 31u));
     };
     const uint32_t d = huff_decode_lit(sh, peek(pos));
     if (d == 0xffffffffu) return 0u;
@@ -513,14 +521,14 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
 {
     uint32_t pos = start;
     uint32_t wi = pos >> 5;
-    uint64_t buf = ((uint64_t)sh.win[wi] | ((uint64_t)sh.win[wi + 1] << 32)) >> (pos & 31u);
+    uint64_t buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
     int nb = 64 - (int)(pos & 31u);
     wi += 2;
     uint8_t *p = out;            /* where the low byte of acc goes */
     unsigned long long acc = 0;  /* pending bytes */
     uint32_t fill = 0;           /* bytes held in acc (< 4 at the top of the loop) */
     while (pos < limit) {
-        if (nb < 32) { buf |= (uint64_t)sh.win[wi++] << nb; nb += 32; }
+        if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
         const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
         uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
         uint32_t pair = 0; /* two literals taken in one step: first | second << 8 */
@@ -542,7 +550,7 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
             if (g & WG_LIT) last = (g >> 18) & 0xffu;
             pos += t;
             wi = pos >> 5;
-            buf = ((uint64_t)sh.win[wi] | ((uint64_t)sh.win[wi + 1] << 32)) >> (pos & 31u);
+            buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
             nb = 64 - (int)(pos & 31u);
             wi += 2;
         }
@@ -658,6 +666,7 @@ __device__ __forceinline__ WinScan window_scan(ParShared &sh, int tid, uint32_t 
 }
 
 /* stage `nwords` dwords of the payload starting at the dword that holds payload bit `bit` */
+template <bool SKEW = false>
 __device__ __forceinline__ uint32_t stage_bits(uint32_t *dst, int nwords, const uint8_t *rec, uint64_t reclen,
                                                uint64_t paybit0, uint32_t bit)
 {
@@ -672,7 +681,7 @@ __device__ __forceinline__ uint32_t stage_bits(uint32_t *dst, int nwords, const 
         else if (wi * 4 < reclen) { /* ragged tail of the records buffer */
             for (uint64_t k = wi * 4; k < reclen; k++) v |= (uint32_t)rec[k] << (8 * (k - wi * 4));
         }
-        dst[i] = v;
+        dst[SKEW ? WSK(i) : i] = v;
     }
     return (uint32_t)(gbit & 31u);
 }
@@ -1028,7 +1037,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         uint32_t nw = SUBBITS / 32;
         if (hint_end > wcur && hint_end - wcur < (uint32_t)WINBITS) nw = (hint_end - wcur + (uint32_t)PT * 32u - 1u) / ((uint32_t)PT * 32u); /* 1..8 */
         const uint32_t sub = 32u * nw;
-        const uint32_t wlead = stage_bits(sh.win, (int)((uint32_t)PT * nw) + 8, sv.rec, sv.reclen, sv.paybit0, wcur);
+        const uint32_t wlead = stage_bits<true>(sh.win, (int)((uint32_t)PT * nw) + 8, sv.rec, sv.reclen, sv.paybit0, wcur);
         __syncthreads();
         PHASE(1);
         const uint32_t pstart = wlead + (uint32_t)tid * sub;
