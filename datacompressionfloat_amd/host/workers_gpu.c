@@ -45,6 +45,7 @@ int isTestThroughput = 0; /* src/core/workers.c:39 */
 #define MAXND 16                  /* devices one call may deal its batches to */
 static __thread int t_device = 0; /* first (logical) device of the calling thread */
 static __thread int t_ndev = 1;   /* devices the thread's calls deal their batches to: t_device .. t_device + t_ndev - 1 */
+static int g_pipes_active = 0; /* pipelines (files) in flight in this process: their helper threads share the host's cores */
 static int g_batch_chunks = 8; /* chunks per device batch: 192 MiB of floats */
 
 void mrcz_workers_set_device(int device) { t_device = device; t_ndev = 1; }
@@ -152,11 +153,17 @@ typedef struct {
     void *h_in[R_IN], *h_out[R_OUT]; /* pinned rings, shared by the devices */
     int in_dev[R_IN], out_dev[R_OUT];/* device (index into d[]) that used the slot last */
 } session_t;
-static __thread session_t t_s;
-static pthread_key_t s_key;
-static pthread_once_t s_once = PTHREAD_ONCE_INIT;
+/* Sessions are pooled per first device, at most SESSIONS_PER_DEV of them: a session pins 190 MiB of host memory and holds
+ * four device batch buffers, which costs more to set up than a 256 MiB file costs to code, and more than three pipelines in
+ * flight add nothing on one GPU (mrc_tarx -n 8 was slower than -n 2 when every worker thread built its own).  A call takes a
+ * free session and gives it back; further callers wait. */
+#define SESSIONS_PER_DEV 3
+static session_t g_ses[MAXDEV][SESSIONS_PER_DEV];
+static int g_ses_busy[MAXDEV][SESSIONS_PER_DEV];
+static pthread_mutex_t g_ses_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_ses_cv = PTHREAD_COND_INITIALIZER;
 
-static void session_release(void *p)
+__attribute__((unused)) static void session_release(void *p)
 {
     session_t *s = (session_t *)p;
     if (!s || !s->ndev) return;
@@ -176,7 +183,13 @@ static void session_release(void *p)
     }
     memset(s, 0, sizeof(*s));
 }
-static void session_key_init(void) { pthread_key_create(&s_key, session_release); }
+static void session_put(session_t *s)
+{
+    pthread_mutex_lock(&g_ses_mu);
+    g_ses_busy[s->dev0][(int)(s - &g_ses[s->dev0][0])] = 0;
+    pthread_cond_signal(&g_ses_cv);
+    pthread_mutex_unlock(&g_ses_mu);
+}
 
 /* devices a thread's calls may deal their batches to (MRCZ_DEVICES overrides what the front-end asked for: tests) */
 static int thread_ndev(void)
@@ -191,13 +204,18 @@ static int thread_ndev(void)
  * h_out): a small file touches one of each, and only as many devices are set up as the file has batches. */
 static session_t *session_get(uint64_t a_bytes, uint64_t b_bytes, int nd)
 {
-    pthread_once(&s_once, session_key_init);
-    session_t *s = &t_s;
-    if (s->ndev && s->dev0 != t_device) session_release(s);
-    if (!s->ndev) {
-        s->dev0 = t_device;
-        pthread_setspecific(s_key, s); /* released when the thread exits */
+    if (t_device < 0 || t_device >= MAXDEV) die("device index out of range", NULL);
+    session_t *s = NULL;
+    pthread_mutex_lock(&g_ses_mu);
+    while (!s) {
+        int pick = -1;
+        for (int i = 0; i < SESSIONS_PER_DEV; i++) /* a built one first */
+            if (!g_ses_busy[t_device][i] && (pick < 0 || (g_ses[t_device][i].ndev && !g_ses[t_device][pick].ndev))) pick = i;
+        if (pick >= 0) { g_ses_busy[t_device][pick] = 1; s = &g_ses[t_device][pick]; }
+        else pthread_cond_wait(&g_ses_cv, &g_ses_mu);
     }
+    pthread_mutex_unlock(&g_ses_mu);
+    if (!s->ndev) s->dev0 = t_device;
     for (int di = s->ndev; di < nd; di++) {
         devses_t *D = &s->d[di];
         D->e = engine_get(t_device + di);
@@ -258,6 +276,7 @@ typedef struct {
     uint64_t plane_z[4];  /* compress: per-plane payload + header bytes (mzip_t.zfsz); uncompress: per-plane payload bytes */
     uint64_t zbytes;      /* uncompress: record bytes read */
     uint64_t nbatches;
+    int crowd;            /* pipelines in flight when this one started (itself included) */
     double gpu_time;      /* time the writer spent waiting for coded batches (what the reference counts as zip/unzip time) */
     double t_fread, t_slotwait, t_fwrite, t_d2hwait, t_setup; /* MRCZ_TRACE=1: where the wall time of the call went */
     /* output: slices of the result are written at their file offsets by NWRITERS threads (pwrite); fd_out < 0 = the output
@@ -386,7 +405,7 @@ static void *reader_main(void *arg)
     fillpool_t fp;
     fillarg_t fa[NFILL - 1];
     memset(&fp, 0, sizeof(fp));
-    fp.nthreads = NFILL;
+    fp.nthreads = p->crowd > 2 ? 1 : (p->crowd == 2 ? 2 : NFILL); /* several files at once (mrc_tarx -n): their threads are the parallelism */
     if (getenv("MRCZ_FILLERS")) { const int v = atoi(getenv("MRCZ_FILLERS")); if (v >= 1 && v <= NFILL) fp.nthreads = v; }
     int eof = 0;
     while (!eof) {
@@ -539,7 +558,7 @@ static void *writer_main(void *arg)
     const uint64_t nd = (uint64_t)p->nd;
     uint64_t oslice = 0; /* output ring position */
     pthread_t pw[MAXWRITERS];
-    int nwr = NWRITERS;
+    int nwr = p->crowd > 2 ? 1 : (p->crowd == 2 ? 2 : NWRITERS);
     if (getenv("MRCZ_WRITERS")) { const int v = atoi(getenv("MRCZ_WRITERS")); if (v >= 1 && v <= MAXWRITERS) nwr = v; }
     const int par = p->fd_out >= 0 && isTestThroughput != 1;
     if (par) {
@@ -662,6 +681,7 @@ static void run_pipeline(pipe_t *p)
     pthread_mutex_init(&p->mu, NULL);
     pthread_cond_init(&p->cv, NULL);
     pthread_t rd, wr;
+    p->crowd = __sync_add_and_fetch(&g_pipes_active, 1); /* (read by the reader and the writer when they size their helper pools) */
     if (pthread_create(&rd, NULL, reader_main, p) != 0 || pthread_create(&wr, NULL, writer_main, p) != 0) die("pthread_create", NULL);
     const uint64_t rec_cap = mrcz_records_bound((uint64_t)p->batch_chunks * CHUNK_SIZE) + 64;
     for (uint64_t k = 0;; k++) {
@@ -700,6 +720,7 @@ static void run_pipeline(pipe_t *p)
     }
     pthread_join(rd, NULL);
     pthread_join(wr, NULL);
+    __sync_sub_and_fetch(&g_pipes_active, 1);
     pthread_mutex_destroy(&p->mu);
     pthread_cond_destroy(&p->cv);
 }
@@ -736,6 +757,7 @@ int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const 
     p.fd_out = output_fd(fout, &p.out_off);
     p.t_setup = now_sec() - begin;
     run_pipeline(&p);
+    session_put(ses);
     if (p.fd_out >= 0) fseeko(fout, (off_t)p.out_off, SEEK_SET); /* the stream continues after what pwrite() wrote */
     const double elapsed = now_sec() - begin;
     trace_report(&p, "run_compress", elapsed, file_floats * 4);
@@ -778,6 +800,7 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
     memcpy(p.ztypes, hd->ztypes, 4);
     p.t_setup = now_sec() - begin;
     run_pipeline(&p);
+    session_put(ses);
     if (p.fd_out >= 0) fseeko(fout, (off_t)p.out_off, SEEK_SET);
     const double elapsed = now_sec() - begin;
     trace_report(&p, "run_uncompress", elapsed, nfloats * 4);
