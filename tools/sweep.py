@@ -79,8 +79,12 @@ with tempfile.TemporaryDirectory(dir=shm) as d:
     volume(n).cpu().numpy().tofile(src)
     tool = os.path.join(ROOT, "datacompressionfloat_amd", "bin", "mrc_tar")
     e2e = {}
+    torch.cuda.empty_cache()  # (this process keeps its GPU context while the tools run: their start-up is slower than stand-alone,
+    #  tools/jobs/cli_wall_times.sh measures them without it)
     for name, cmd in (("zip", [tool, "-i", src, "-o", z, "-t", "zip", "-b", "8"]), ("unzip", [tool, "-i", z, "-o", back, "-t", "unzip"])):
         subprocess.run(cmd, stdout=subprocess.DEVNULL, check=True)  # warm (page cache, context creation)
+        if name == "unzip" and os.path.exists(back):
+            os.remove(back)  # (freeing a 1 GiB tmpfs file is not part of the tool's work)
         t0 = time.perf_counter()
         subprocess.run(cmd, stdout=subprocess.DEVNULL, check=True)
         dt = time.perf_counter() - t0
