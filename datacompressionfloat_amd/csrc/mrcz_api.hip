@@ -65,7 +65,7 @@ struct mrcz_ctx {
     uint32_t *fallback;
     Cand *cands;           /* block-start candidates, MAXCAND per stream */
     uint32_t *ncand;       /* [ns] candidate counts, then [ns + 1] prefix, then job counter */
-    uint32_t *candbase;
+    uint32_t *candbase, *jobord; /* job numbering of the block decoder: prefix of the candidate counts over the streams in job order */
     Seg *segs;             /* where the plane bytes of every decoded stream are (MAXSEG per stream) */
     uint32_t *nseg;
     uint16_t *segidx;      /* first segment of every merge tile (MTILES per stream) */
@@ -189,6 +189,7 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     if (e == hipSuccess) e = dalloc(&ctx->cands, ns * MAXCAND);
     if (e == hipSuccess) e = dalloc(&ctx->ncand, ns);
     if (e == hipSuccess) e = dalloc(&ctx->candbase, ns + 1);
+    if (e == hipSuccess) e = dalloc(&ctx->jobord, ns);
     if (e == hipSuccess) e = dalloc(&ctx->segs, ns * MAXSEG);
     if (e == hipSuccess) e = dalloc(&ctx->nseg, ns);
     if (e == hipSuccess) e = dalloc(&ctx->segidx, ns * MTILES);
@@ -222,7 +223,7 @@ extern "C" void mrcz_destroy(mrcz_ctx_t *ctx)
     (void)hipFree(ctx->tsum); (void)hipFree(ctx->tinfo); (void)hipFree(ctx->sinfo); (void)hipFree(ctx->blkstart);
     (void)hipFree(ctx->slideq); (void)hipFree(ctx->pairhist); (void)hipFree(ctx->blkfreq); (void)hipFree(ctx->blkcode);
     (void)hipFree(ctx->blkhdr); (void)hipFree(ctx->meta); (void)hipFree(ctx->lay); (void)hipFree(ctx->pairbits);
-    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->segs); (void)hipFree(ctx->nseg); (void)hipFree(ctx->segidx); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->scratch); (void)hipFree(ctx->hdrs); (void)hipFree(ctx->njobs);
+    (void)hipFree(ctx->pairoff); (void)hipFree(ctx->blkbase); (void)hipFree(ctx->result); (void)hipFree(ctx->dstreams); (void)hipFree(ctx->fallback); (void)hipFree(ctx->cands); (void)hipFree(ctx->ncand); (void)hipFree(ctx->candbase); (void)hipFree(ctx->jobord); (void)hipFree(ctx->segs); (void)hipFree(ctx->nseg); (void)hipFree(ctx->segidx); (void)hipFree(ctx->rawlist); (void)hipFree(ctx->scratch); (void)hipFree(ctx->hdrs); (void)hipFree(ctx->njobs);
     (void)hipFree(ctx->dbgphase);
     (void)hipFree(ctx->planes);
     (void)hipFree(ctx->errhist);
@@ -550,9 +551,9 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
                    ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 4, ctx->rawcap);
             LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 4,
                    ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag);
-            LAUNCH("k_cand_index", k_cand_index, dim3(1), dim3(256), ctx->ncand, ns, ctx->candbase);
+            LAUNCH("k_cand_index", k_cand_index, dim3(1), dim3(256), ctx->ncand, ctx->dstreams, ns, ctx->candbase, ctx->jobord);
             /* fixed grid: the workgroups pull candidate numbers from ctx->njobs[0] until it passes candbase[ns] (no read-back) */
-            LAUNCH("k_blk_count", k_blk_count, dim3(ctx->blk_grid), dim3(PT), rec, len, ctx->dstreams, ns, ctx->candbase,
+            LAUNCH("k_blk_count", k_blk_count, dim3(ctx->blk_grid), dim3(PT), rec, len, ctx->dstreams, ns, ctx->candbase, ctx->jobord,
                      ctx->cands, ctx->scratch + 16, ctx->njobs + 2, (uint32_t)(ctx->scratch_bytes >> 4), ctx->hdrs, ctx->calltag, ctx->njobs,
                      ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL, ctx->use_hint);
         }
