@@ -406,7 +406,7 @@ struct SubResult {
 /* P3: count walk.  Decode tokens from window bit `start` until the position reaches `limit` (or
  * END_BLOCK), counting the plane bytes they produce.  Nearly every token is sized by the two fast
  * tables (token bits, produced bytes) with a single 12-bit lookup each. */
-template <bool TRACK_LAST, bool STOP_AT_LIT = false, bool DBL = false>
+template <bool TRACK_LAST, bool STOP_AT_LIT = false, bool DBL = false, bool NLIT = false /* count literal tokens instead of bytes */>
 __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t start, uint32_t limit)
 {
     SubResult r;
@@ -438,7 +438,7 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
         if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) { /* 1 <= t <= MAXTOK, distance 1 */
             if (STOP_AT_LIT && n == 1u) break;
             buf >>= t; nb -= (int)t; pos += t;
-            r.nout += n;
+            r.nout += NLIT ? (n == 1u ? 1u : 0u) : n;
             if (TRACK_LAST && n == 1u) r.lastlit = 0x100u | ((e >> TOK_SYM_SHIFT) & 0xffu);
             continue;
         }
@@ -474,7 +474,7 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
             const uint32_t dist = base_dist_of(dc) + ((uint32_t)buf & ((1u << dxb) - 1u));
             buf >>= dxb; nb -= dxb; pos += (uint32_t)dxb;
             if (dist != 1u) r.flags |= F_GENERAL;
-            r.nout += ml;
+            r.nout += NLIT ? 0u : ml;
         }
     }
     r.land = pos;
@@ -626,7 +626,7 @@ __device__ __forceinline__ uint32_t block_min_pt(uint32_t v, uint32_t *wtot)
 /* Everything a window needs from the lanes' count walks, with ONE workgroup barrier (five separate scans cost ten): the
  * exclusive prefix sum of the bytes produced and their total, the last literal decoded by a lane before this one, the
  * first lane that ended the block or failed, the failure kinds seen, the first lane that decoded a literal. */
-struct WinScan { uint32_t myoff, total, before, stop_tid, bad, firstlit_tid; };
+struct WinScan { uint32_t myoff, total, before, stop_tid, bad, firstlit_tid, lit_after0 /* a lane other than thread 0 decoded a literal */; };
 __device__ __forceinline__ WinScan window_scan(ParShared &sh, int tid, uint32_t nout, uint32_t lastlit, uint32_t flags)
 {
     const int l = lane_id(), w = tid >> 6;
@@ -641,7 +641,7 @@ __device__ __forceinline__ WinScan window_scan(ParShared &sh, int tid, uint32_t 
     if (l == 63) { sh.scan_a[w] = x; sh.scan_b[w] = ll; }
     if (l == 0) {
         sh.scan_c[w] = bstop ? (uint32_t)(64 * w + ctz64(bstop)) : 0xffffffffu;
-        sh.scan_d[w] = (bgen ? (uint32_t)F_GENERAL : 0u) | (berr ? (uint32_t)F_ERR : 0u);
+        sh.scan_d[w] = (bgen ? (uint32_t)F_GENERAL : 0u) | (berr ? (uint32_t)F_ERR : 0u) | (((w == 0 ? blit & ~1ull : blit) != 0ull) ? 0x100u : 0u);
         sh.scan_e[w] = blit ? (uint32_t)(64 * w + ctz64(blit)) : 0xffffffffu;
     }
     uint32_t e1 = __shfl_up(ll, 1);
@@ -659,6 +659,8 @@ __device__ __forceinline__ WinScan window_scan(ParShared &sh, int tid, uint32_t 
         r.firstlit_tid = te < r.firstlit_tid ? te : r.firstlit_tid;
         r.bad |= sh.scan_d[i];
     }
+    r.lit_after0 = r.bad >> 8;
+    r.bad &= 0xffu;
     r.myoff = pre + x - nout;
     r.total = tot;
     r.before = e1 ? e1 : prelast;
@@ -825,6 +827,7 @@ struct HdrCache {
     uint8_t lens[320];
 };
 __device__ __forceinline__ uint32_t hdr_tag(uint32_t calltag, uint32_t bit) { return (calltag ^ (bit * 0x9e3779b1u)) | 1u; }
+constexpr uint32_t WB_CONST_LEAD = 0xfffffdffu, WB_CONST = 0xfffffe00u; /* ScratchOut::wbase values of windows that are not stored (below) */
 constexpr int CAND_WINDOWS = 5;   /* windows (32 KiB of compressed bits each) a speculatively decoded block may span */
 
 /* where a speculatively decoded block leaves its bytes: k_blk_count cannot know the block's place in the plane yet
@@ -1127,10 +1130,21 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         uint8_t *wout;
         if (MODE == MODE_SCRATCH) {
             if (tid == 0) {
-                const uint32_t units = (total + 15u) >> 4;
+                /* A window whose bytes are all the same -- no literal in it, or one and that is its first token: a plane masked
+                 * to zero is one such window of 6 MiB per chunk -- is not written at all: the segment the chain builds for it is
+                 * a fill.  Only thread 0 can hold the literal then, and it counts its literals with one more walk. */
+                uint32_t wconst = 0; /* 0 = ordinary window, else WB_CONST | byte, or WB_CONST_LEAD (bytes before the block's first literal) */
+                if (!ws.lit_after0 && total != 0u) {
+                    uint32_t nl = 0;
+                    if (r.lastlit) nl = dbl ? count_walk<false, false, true, true>(sh, start, limit).nout : count_walk<false, false, false, true>(sh, start, limit).nout;
+                    if (nl == 0u) wconst = haslit0 ? (WB_CONST | (lastin & 0xffu)) : WB_CONST_LEAD;
+                    else if (nl == 1u && (dbl ? count_walk<false, true, true>(sh, start, limit).nout : count_walk<false, true>(sh, start, limit).nout) == 0u)
+                        wconst = WB_CONST | (r.lastlit & 0xffu);
+                }
+                const uint32_t units = wconst ? 0u : (total + 15u) >> 4;
                 uint32_t b16 = 0xffffffffu;
                 if (widx <= (uint32_t)CAND_WINDOWS) { /* widx already counts this window */
-                    b16 = units ? atomicAdd(so.top, units) : 0u;
+                    b16 = units ? atomicAdd(so.top, units) : wconst;
                     if (units && (b16 > so.cap16 || units > so.cap16 - b16)) b16 = 0xffffffffu;
                     so.wbase[widx - 1u] = b16;
                     so.wlen[widx - 1u] = total;
@@ -1144,14 +1158,14 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
                 __syncthreads();
                 break;
             }
-            wout = so.base + (size_t)sh.wbase * 16u + myoff;
+            wout = (sh.wbase >= WB_CONST_LEAD) ? nullptr : so.base + (size_t)sh.wbase * 16u + myoff;
             if (!haslit0) {
                 /* the bytes in front of the block's first literal replicate the previous block's last byte, which is
                  * not known here: remember how many there are, the merge fills them in */
                 if ((uint32_t)tid == ws.firstlit_tid) sh.lead = op + myoff + (dbl ? count_walk<false, true, true>(sh, start, limit).nout : count_walk<false, true>(sh, start, limit).nout);
             }
         } else wout = sv.out + op + myoff;
-        if (active && r.nout) {
+        if (active && r.nout && wout) {
             if (dbl) write_walk<true>(sh, start, limit, wout, before ? (before & 0xffu) : lastin);
             else write_walk<false>(sh, start, limit, wout, before ? (before & 0xffu) : lastin);
         }
@@ -1521,24 +1535,55 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
  * single workgroup) comes first, the others follow in stream order: the persistent grid then ends on short jobs instead of
  * idling while a few long ones finish (b = 8: 3.53 -> 3.47 ms).  Numbering whole planes one after the other was tried and is
  * worse for most mask levels: the mix of planes in stream order keeps workgroups in different phases beside each other. */
+/* exclusive prefix sum of v over the 256 threads of the workgroup (wsum: 4 words of LDS); *total = the sum */
+__device__ __forceinline__ uint32_t scan256(uint32_t v, uint32_t *wsum, uint32_t *total)
+{
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t x = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (l >= d) x += y; }
+    if (l == 63) wsum[w] = x;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (int i = 0; i < 4; i++) { const uint32_t t = wsum[i]; if (i < w) pre += t; tot += t; }
+    __syncthreads();
+    *total = tot;
+    return pre + x - v;
+}
 __global__ __launch_bounds__(256) void k_cand_index(const uint32_t *__restrict__ ncand, const DecStream *__restrict__ ds, uint32_t nstreams,
                                                     uint32_t *__restrict__ candbase /* [nstreams + 1] */, uint32_t *__restrict__ jobord /* [nstreams] */)
 {
-    if (threadIdx.x != 0) return;
-    uint32_t k = 0;
-    for (int pass = 0; pass < 2; pass++)
-        for (uint32_t s = 0; s < nstreams; s++) {
-            const uint32_t c = ncand[s] < (uint32_t)MAXCAND ? ncand[s] : (uint32_t)MAXCAND;
-            const bool longjobs = c != 0u && !ds[s].raw && ds[s].n / c >= 262144u;
-            if (longjobs == (pass == 0)) jobord[k++] = s;
+    /* nstreams <= 512: two consecutive streams per thread */
+    __shared__ uint32_t wsum[4], cj[512];
+    const uint32_t t = threadIdx.x;
+    uint32_t c[2], lg[2];
+    for (int j = 0; j < 2; j++) {
+        const uint32_t s = 2u * t + (uint32_t)j;
+        c[j] = 0; lg[j] = 0;
+        if (s < nstreams) {
+            c[j] = ncand[s] < (uint32_t)MAXCAND ? ncand[s] : (uint32_t)MAXCAND;
+            const DecStream d = ds[s];
+            lg[j] = (c[j] != 0u && !d.raw && d.n / c[j] >= 262144u) ? 1u : 0u;
         }
-    uint32_t run = 0;
-    for (uint32_t i = 0; i < nstreams; i++) {
-        candbase[i] = run;
-        const uint32_t c = ncand[jobord[i]];
-        run += c < (uint32_t)MAXCAND ? c : (uint32_t)MAXCAND;
     }
-    candbase[nstreams] = run;
+    uint32_t nlong, nshort;
+    const uint32_t plong = scan256(lg[0] + lg[1], wsum, &nlong);
+    const uint32_t inr0 = 2u * t < nstreams ? 1u : 0u, inr1 = 2u * t + 1u < nstreams ? 1u : 0u;
+    const uint32_t pshort = scan256((inr0 & (lg[0] ^ 1u)) + (inr1 & (lg[1] ^ 1u)), wsum, &nshort);
+    uint32_t kl = plong, ks = nlong + pshort;
+    for (int j = 0; j < 2; j++) {
+        const uint32_t s = 2u * t + (uint32_t)j;
+        if (s >= nstreams) continue;
+        const uint32_t pos = lg[j] ? kl++ : ks++; /* the stream's place in job order */
+        jobord[pos] = s;
+        cj[pos] = c[j];
+    }
+    __syncthreads();
+    const uint32_t a0 = 2u * t < nstreams ? cj[2u * t] : 0u, a1 = 2u * t + 1u < nstreams ? cj[2u * t + 1u] : 0u;
+    uint32_t total;
+    const uint32_t pre = scan256(a0 + a1, wsum, &total);
+    if (2u * t < nstreams) candbase[2u * t] = pre;
+    if (2u * t + 1u < nstreams) candbase[2u * t + 1u] = pre + a0;
+    if (t == 0) candbase[nstreams] = total;
 }
 
 /* D2: decode every candidate block as if it were real: where does it end, how many plane bytes does it produce, what is
@@ -1754,6 +1799,11 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
             Seg g;
             g.src = stored ? (SEG_REC | (d.payoff + wb[w])) : (uint64_t)wb[w] * 16ull;
             g.dst = p; g.len = l; g.fill_until = boff + lead; g.fillb = bl;
+            if (!stored && wb[w] >= WB_CONST_LEAD) { /* a window of equal bytes, never written: the segment is a fill */
+                g.src = 0;
+                if (wb[w] >= WB_CONST) { g.fill_until = p + l; g.fillb = wb[w] & 0xffu; }
+                else if (g.fill_until < p + l) g.fill_until = p + l; /* (such a window lies in front of the block's first literal: it is inside the lead anyway) */
+            }
             sg[k] = g;
             /* tiles whose first position lies in this segment (a window holds a few; the megabyte-long windows of an
              * all-zero plane are one or two per stream) */
@@ -1892,7 +1942,7 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
         const bool adj = B.len != 0u && B.dst == aend && A.len != 0u;
         /* four independent 16-byte loads per lane first (destination-aligned groups, source at any alignment), patches after */
         uint4 v[MTILE / 16 / 64], v2 = make_uint4(0, 0, 0, 0); /* (one boundary A | B: at most one straddling group per lane) */
-        uint32_t kind[MTILE / 16 / 64]; /* 0 zero, 1 inside A, 2 inside B, 3 straddles A | B, 4 general path */
+        uint32_t kind[MTILE / 16 / 64]; /* 0 zero, 1 inside A, 2 inside B, 3 straddles A | B, 4 general path, 5 / 6 inside A's / B's fill */
 #pragma unroll
         for (int j = 0; j < MTILE / 16 / 64; j++) {
             const uint32_t g = (uint32_t)lane + 64u * (uint32_t)j, p = p0 + 16u * g;
@@ -1903,6 +1953,10 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
             else if (whole && inB) kd = 2u;
             else if (whole && adj && p >= A.dst && p < aend && p + 16u <= bend && p >= A.fill_until && B.fill_until <= B.dst &&
                      seg_can_overread(sb, A.src, (int64_t)(p - A.dst)) && seg_can_overread(sb, B.src, (int64_t)p - (int64_t)B.dst)) kd = 3u;
+            /* a group that lies inside a segment's fill (leading repeats of a block, a window of equal bytes that was never
+             * written) is not loaded at all */
+            if (kd == 1u && p + 16u <= A.fill_until) kd = 5u;
+            if (kd == 2u && p + 16u <= B.fill_until) kd = 6u;
             kind[j] = kd;
             v[j] = make_uint4(0, 0, 0, 0);
             if (kd == 1u || kd == 3u) __builtin_memcpy(&v[j], abase + (p - A.dst), 16);
@@ -1921,6 +1975,9 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
                     const uint32_t fw = 0x01010101u * ((kind[j] == 1u ? A.fillb : B.fillb) & 0xffu);
                     v[j] = blend16(make_uint4(fw, fw, fw, fw), v[j], fu - p >= 16u ? 16u : fu - p);
                 }
+            } else if (kind[j] == 5u || kind[j] == 6u) {
+                const uint32_t fw = 0x01010101u * ((kind[j] == 5u ? A.fillb : B.fillb) & 0xffu);
+                v[j] = make_uint4(fw, fw, fw, fw);
             } else if (kind[j] == 3u) v[j] = blend16(v[j], v2, aend - p);
             else if (kind[j] == 4u) v[j] = merge_slow16(sb, sg, ns, p, pend, k0);
             tile[w][g] = v[j];
