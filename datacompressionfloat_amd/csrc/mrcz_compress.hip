@@ -790,7 +790,9 @@ __global__ __launch_bounds__(256) void k_container(StreamInfo *__restrict__ sinf
 /* ======================================================================================
  * emit
  * ==================================================================================== */
-constexpr int STAGE_WORDS = 2048; /* 8 KiB per wave: 4096 symbols x <= 15 bits = 7680 B + alignment */
+constexpr int STAGE_WORDS = 1280; /* 5 KiB per wave.  A tile's 4096 symbols are <= 15 bits each (7680 B), but a coded block averages under
+                                    * eight bits a symbol or it would have been stored: 5 KiB hold nearly every tile, and one that does not fit is
+                                    * emitted in two halves.  The 3 KiB are what lets more emit waves sit beside the other lane's Huffman trees. */
 
 /* OR `nbits` (<= 32) bits of `val` into the bit string at absolute bit position `pos` of a zeroed
  * device buffer (32-bit atomics: neighbouring writers share boundary words) */
@@ -972,9 +974,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EMIT_WAVES))
             mode = -1;
         }
 
-        /* a tile may straddle one block boundary: process [part 0 | part 1] */
+        /* a tile may straddle one block boundary: process [part 0 | part 1]; and a part whose bits exceed the staging buffer is cut
+         * in two (cap) and taken again */
         int pos0 = 0; /* tile-relative start of the part */
-        for (int part = 0; part < 2 && pos0 < len; part++) {
+        int cap = len; /* the part ends here at the latest */
+        for (int part = 0; part < 16 && pos0 < len; part++) {
             if (mode < 0 || t0 + (uint32_t)pos0 >= blkEnd) {
                 if (mode >= 0) curBlk++;
                 const BlkLay L = blay[curBlk];
@@ -999,8 +1003,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EMIT_WAVES))
                     __builtin_amdgcn_wave_barrier(); /* lut visible to the whole wave */
                 }
             }
-            int pos1 = len; /* tile-relative end of the part */
-            if (blkEnd < t0 + (uint32_t)len) pos1 = (int)(blkEnd - t0);
+            int pos1 = cap; /* tile-relative end of the part */
+            if (blkEnd < t0 + (uint32_t)pos1) pos1 = (int)(blkEnd - t0);
 
             if (mode == 0) {
                 /* STORED block: plane bytes [pos0, pos1) go out verbatim at a byte-aligned address.  The wave assembles
@@ -1025,7 +1029,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EMIT_WAVES))
                     else if (v) atomicOr(&out32[w0 + k], v);
                 }
                 cur += 8u * nbytes;
-                pos0 = pos1;
+                pos0 = pos1; cap = len;
                 continue;
             }
             /* lane-relative part mask */
@@ -1037,7 +1041,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EMIT_WAVES))
 
             /* pass A: bits produced by this lane.  The table reads of a quarter are independent (unrolled, bytes come from
              * registers), so their LDS latency overlaps; matches are rare and handled apart. */
-            if (__ballot(S != 0ull) == 0ull) { pos0 = pos1; continue; } /* no symbol starts in this part (inside long runs) */
+            if (__ballot(S != 0ull) == 0ull) { pos0 = pos1; cap = len; continue; } /* no symbol starts in this part (inside long runs) */
             uint32_t lbits = 0;
             {
                 const uint64_t L = S & ~M;
@@ -1063,6 +1067,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EMIT_WAVES))
                 const uint64_t gbit = paybit + cur;
                 const uint32_t lead = (uint32_t)(gbit & 31u);
                 const uint32_t nwords = (lead + tot + 31u) >> 5;
+                if (nwords > (uint32_t)STAGE_WORDS) { /* (wave-uniform; one lane's 64 symbols always fit) */
+                    cap = pos0 + ((((pos1 - pos0) >> 1) + 63) & ~63);
+                    continue;
+                }
                 for (uint32_t i = lane; i < nwords; i += 64) stage[i] = 0;
                 __builtin_amdgcn_wave_barrier();
                 LanePacker pk;
@@ -1085,7 +1093,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EMIT_WAVES))
                 __builtin_amdgcn_wave_barrier();
                 cur += tot;
             }
-            pos0 = pos1;
+            pos0 = pos1; cap = len;
         }
     }
 }

@@ -132,6 +132,14 @@ def test_skewed_alphabets_force_length_overflow(codec, oracle):
     _roundtrip(codec, oracle, np.tile(w, 5), 0)
 
 
+def test_tile_of_long_codes_exceeds_the_emit_staging_buffer(codec, oracle):
+    # see tests/test_sim.py: tiles whose bits do not fit k_emit's staging buffer are emitted in two halves
+    rng = np.random.default_rng(5)
+    common = lambda n: rng.integers(0, 4, n, dtype=np.uint64).astype(np.uint32)
+    rare = (4 + rng.integers(0, 250, 5000, dtype=np.uint64)).astype(np.uint32)
+    _roundtrip(codec, oracle, np.concatenate([common(12000), rare, common(40000), rare, common(300000)]), 0)
+
+
 def test_planes_that_begin_with_stored_blocks(codec, oracle):
     # noise, then constants: the stream of every plane starts with STORED blocks and goes on with coded ones (see tests/test_sim.py)
     rng = np.random.default_rng(11)

@@ -62,6 +62,16 @@ def test_planes_that_begin_with_stored_blocks(simlib, oracle):
         _check(simlib, oracle, w, 0)
 
 
+def test_tile_of_long_codes_exceeds_the_emit_staging_buffer(simlib, oracle):
+    # a block of mostly four frequent byte values (2-bit codes) with a stretch of 250 rare values (10..12-bit codes) that fills whole
+    # tiles: those tiles' bits (4096 x ~12) do not fit k_emit's 5 KiB staging buffer and are emitted in two halves
+    rng = np.random.default_rng(5)
+    common = lambda n: rng.integers(0, 4, n, dtype=np.uint64).astype(np.uint32)
+    rare = (4 + rng.integers(0, 250, 5000, dtype=np.uint64)).astype(np.uint32)
+    w = np.concatenate([common(12000), rare, common(40000)])
+    _check(simlib, oracle, w, 0)
+
+
 def test_kat_a(simlib, oracle):
     w = util.kat_words(300000)
     for b in (0, 23):
