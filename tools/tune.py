@@ -56,7 +56,7 @@ if which == "compress":
         res.append(run({"MRCZ_LANES": lanes, "MRCZ_STAGGER": stagger, "MRCZ_HT": ht}))
         print(json.dumps(res[-1]), flush=True)
 elif which == "split":
-    for split, stagger in [(50, 1), (55, 1), (60, 1), (65, 1), (70, 1), (75, 1), (45, 1), (50, 1)]:
+    for split, stagger in [(50, 1), (55, 1), (60, 1), (45, 1), (65, 1), (75, 1)]:
         res.append(run({"MRCZ_LANES": 2, "MRCZ_STAGGER": stagger, "MRCZ_SPLIT": split}))
         print(json.dumps(res[-1]), flush=True)
     for lanes in (3, 4):
