@@ -1247,8 +1247,8 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
     __shared__ uint32_t queue[SCAN_QCAP];
     __shared__ uint32_t stepw[256 + 8];
     __shared__ uint32_t surv[SURV_CAP];
-    __shared__ uint32_t qn, sn;
-    if (lane == 0) { qn = 0; sn = 0; }
+    __shared__ uint32_t sn;
+    if (lane == 0) sn = 0;
     __builtin_amdgcn_wave_barrier();
     const uint32_t seg = (blockIdx.x * 7u + blockIdx.y) % RAW_SEGS, segcap = rawcap / RAW_SEGS;
     /* hand the collected survivors to the raw list: one reservation for the whole wave */
@@ -1286,6 +1286,8 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
         *reinterpret_cast<uint4 *>(&stepw[4u * lane]) = make_uint4(wc[0], wc[1], wc[2], wc[3]);
         if (lane < 2u) *reinterpret_cast<uint4 *>(&stepw[256u + 4u * lane]) = make_uint4(wn[0], wn[1], wn[2], wn[3]);
         __builtin_amdgcn_wave_barrier();
+        uint32_t hitsv[4];
+        uint32_t nh = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t wnext = j < 3 ? wc[j < 3 ? j + 1 : 3] : stepw[4u * lane + 4u]; /* the next lane's (or step's) first dword */
@@ -1298,18 +1300,26 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
 #define SH(k) __builtin_amdgcn_alignbit(wnext, lo, (k))
             const uint32_t must1 = SH(2) & SH(8);
             const uint32_t must0 = lo | SH(1) | SH(9) | SH(10) | SH(11) | SH(12) | (SH(4) & SH(5) & SH(6) & SH(7));
-            const uint32_t sig = must1 & ~must0;
+            hitsv[j] = must1 & ~must0;
 #undef SH
-            uint32_t hits = sig;
+            nh += (uint32_t)__builtin_popcount(hitsv[j]);
+        }
+        /* queue slots by a wave prefix sum of the lanes' hit counts (a returning LDS atomic per hit was a chain of up to seven
+         * LDS round trips per step) */
+        uint32_t nq;
+        uint32_t slot = wave_excl_sum(nh, &nq);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t hits = hitsv[j];
             while (hits) {
                 const int b = __builtin_ctz(hits);
                 hits &= hits - 1u;
-                const uint32_t slot = atomicAdd(&qn, 1u);
                 if (slot < (uint32_t)SCAN_QCAP) queue[slot] = ((4u * lane + (uint32_t)j) << 5) | (uint32_t)b; /* bit inside the step */
+                slot++;
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const uint32_t pending = qn < (uint32_t)SCAN_QCAP ? qn : (uint32_t)SCAN_QCAP; /* one LDS read for the whole wave: uniform */
+        const uint32_t pending = nq < (uint32_t)SCAN_QCAP ? nq : (uint32_t)SCAN_QCAP;
         const uint64_t step_bit0 = (w_first + (uint64_t)k * 256u) << 5;
         for (uint32_t qr = 0; qr < pending; qr += 64u) {
             if (qr && sn > SURV_CAP - 64u) flush_survivors(); /* wave-uniform (sn is read by the whole wave at once) */
@@ -1340,9 +1350,7 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
             const uint32_t i = atomicAdd(&sn, 1u);
             if (i < SURV_CAP) surv[i] = p; /* validated by k_validate_candidates */
         }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) qn = 0;
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier(); /* the queue's readers are done before the next step refills it */
         if (sn > SURV_CAP - 64u) flush_survivors(); /* a drain round adds at most 64: never overflows (wave-uniform) */
     }
     flush_survivors();
