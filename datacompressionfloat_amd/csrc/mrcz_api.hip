@@ -34,6 +34,7 @@ struct mrcz_ctx {
     hipStream_t lane_stream[MAX_LANES]; /* ... the lanes of a compress batch (see mrcz_compress_chunks); [0] = stream */
     hipEvent_t ev_start, ev_cont, ev_done[MAX_LANES];
     hipEvent_t ev_stream[MAX_LANES]; /* lane l's summary + histogram passes are done */
+    uint32_t huff_split;           /* the blocks' dynamic headers by k_huffman_hdr, one wave per tree (MRCZ_HUFF_SPLIT=0: inside k_huffman, one thread per tree) */
     uint32_t use_hint;             /* block decoder: size the pieces of a window by where the block probably ends (MRCZ_HINT=0: off) */
     uint32_t split_pct;            /* two lanes: share of a batch's chunks (per cent) the first lane takes; MRCZ_SPLIT overrides it */
     int stagger;                   /* lanes start one after the other (each once the previous one's streaming passes are done), so that
@@ -164,6 +165,8 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->huff_ht = 48;
     ctx->split_pct = 55; /* (measured: 50 -> 2.58 ms, 55 -> 2.56, 60 -> 2.60; three lanes, even or uneven, 2.8-2.9) */
     ctx->use_hint = 1;
+    ctx->huff_split = 1;
+    if (const char *ev = getenv("MRCZ_HUFF_SPLIT")) ctx->huff_split = atoi(ev) ? 1u : 0u;
     if (const char *ev = getenv("MRCZ_HINT")) ctx->use_hint = atoi(ev) ? 1u : 0u;
     if (const char *ev = getenv("MRCZ_SPLIT")) { const int v = atoi(ev); if (v >= 5 && v <= 95) ctx->split_pct = (uint32_t)v; }
     if (const char *ev = getenv("MRCZ_STAGGER")) ctx->stagger = atoi(ev) ? 1 : 0;
@@ -352,9 +355,14 @@ static int compress_lane(mrcz_ctx *ctx, hipStream_t lstream, int phase, int slot
         LAUNCH("k_block_index", k_block_index, dim3(1), dim3(256), sinfo, ns, blkbase);
         HIPCHK(hipEventRecord(ctx->ev_stream[slot], lstream), "event"); /* this lane's streaming passes are done: the next lane may start */
         unsigned long long *hdbg = ctx->phase_profile == 3 ? ctx->dbgphase : (unsigned long long *)NULL; /* developer tool */
-        if (ctx->huff_ht == 16) LAUNCH("k_huffman", k_huffman<16>, dim3((ns * MAXBLK + 15) / 16), dim3(16), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
-        else if (ctx->huff_ht == 32) LAUNCH("k_huffman", k_huffman<32>, dim3((ns * MAXBLK + 31) / 32), dim3(32), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
-        else LAUNCH("k_huffman", k_huffman<48>, dim3((ns * MAXBLK + 47) / 48), dim3(48), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
+        if (ctx->huff_split) {
+            /* trees one thread each, then the header of every block one wave each (the grid covers the most blocks a batch can
+             * have; the kernel reads the count from blkbase) */
+            LAUNCH("k_huffman", (k_huffman<48, false>), dim3((ns * MAXBLK + 47) / 48), dim3(48), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
+            LAUNCH("k_huffman_hdr", k_huffman_hdr, dim3(ns * MAXBLK), dim3(64), sinfo, ns, blkbase, blkcode, blkhdr, meta);
+        } else if (ctx->huff_ht == 16) LAUNCH("k_huffman", (k_huffman<16, true>), dim3((ns * MAXBLK + 15) / 16), dim3(16), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
+        else if (ctx->huff_ht == 32) LAUNCH("k_huffman", (k_huffman<32, true>), dim3((ns * MAXBLK + 31) / 32), dim3(32), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
+        else LAUNCH("k_huffman", (k_huffman<48, true>), dim3((ns * MAXBLK + 47) / 48), dim3(48), sinfo, ns, blkbase, blkfreq, blkcode, blkhdr, meta, hdbg);
 
         LAUNCH("k_stream_layout", k_stream_layout, dim3(ns), dim3(64), sinfo, meta, blkstart, slideq, lay);
         LAUNCH("k_pair_bits", k_pair_bits, dim3(SPS, ns), dim3(64), sinfo, lay, pairhist, blkcode, tinfo, pairbits);

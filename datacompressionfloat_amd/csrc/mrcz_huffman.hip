@@ -274,6 +274,100 @@ __device__ __forceinline__ RunStep run_scan_step(RunScan &r, int curlen, int nex
     return o;
 }
 
+/* RFC 1951 order in which the code-length code lengths are sent */
+__device__ __forceinline__ int bl_order(int i)
+{
+    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    return order[i];
+}
+/* build_bl_tree + the bit-length part of opt_len (trees.c): BLFREQ(0..18) are counted, BLLEN are zero.  Leaves BLLEN, BLENT
+ * (code | length << 8) and returns max_blindex; bl_max = highest symbol with a code. */
+template <int HT> __device__ __forceinline__ int bl_tree_build(TreeMem<HT> &tm, int tid, long &opt_len, int &bl_max_out)
+{
+    int overflow = 0;
+    int bn = 0, bl_max = -1;
+    {
+        uint32_t f[BLELEMS];
+#pragma unroll
+        for (int i = 0; i < BLELEMS; i++) f[i] = BLFREQ(i);
+#pragma unroll
+        for (int i = 0; i < BLELEMS; i++)
+            if (f[i]) { bn++; HEAP(bn) = (f[i] << 16) | (uint32_t)i; bl_max = i; }
+    }
+    while (bn < 2) { /* zlib: force at least two codes of non zero frequency */
+        const int node = bl_max < 2 ? ++bl_max : 0;
+        BLFREQ(node) = 1;
+        bn++;
+        HEAP(bn) = (1u << 16) | (uint32_t)node;
+        opt_len--;
+    }
+    uint32_t blmerged = 0;
+    const int bniter = merge_loop<HT>(tm.heap, tid, bn, BLELEMS, &blmerged);
+#pragma unroll
+    for (int i = 0; i < 16; i++) BLCOUNT(i) = 0;
+    overflow = 0;
+    for (int it = bniter - 1; it >= 0; it--) {
+        const uint32_t w = HEAP(bn - it);
+        const int L = (int)((w >> 20) & 31u);
+        for (int side = 1; side >= 0; side--) {
+            const int child = (int)(side ? (w >> 10) & 0x3ffu : w & 0x3ffu);
+            int bits = L + 1;
+            if (bits > 7) { bits = 7; overflow++; }
+            if (child >= BLELEMS) { HEAP(bn - (child - BLELEMS)) |= (uint32_t)bits << 20; continue; }
+            BLLEN(child) = (uint32_t)bits;
+            BLCOUNT(bits) = BLCOUNT(bits) + 1;
+        }
+    }
+    if (overflow > 0) {
+        do {
+            int bits = 6;
+            while (BLCOUNT(bits) == 0) bits--;
+            BLCOUNT(bits) = BLCOUNT(bits) - 1;
+            BLCOUNT(bits + 1) = BLCOUNT(bits + 1) + 2;
+            BLCOUNT(7) = BLCOUNT(7) - 1;
+            overflow -= 2;
+        } while (overflow > 0);
+        int h = 0;
+        for (int bits = 7; bits != 0; bits--) {
+            int cnt = (int)BLCOUNT(bits);
+            while (cnt != 0) {
+                const int m = removed_node<HT>(tm.heap, tid, bn, h);
+                h++;
+                if (m >= BLELEMS) continue;
+                if ((int)BLLEN(m) != bits) BLLEN(m) = (uint32_t)bits;
+                cnt--;
+            }
+        }
+    }
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int bits = 1; bits <= 7; bits++) {
+            c = (c + BLCOUNT(bits - 1)) << 1;
+            NEXTCODE(bits) = c;
+        }
+        for (int sym = 0; sym <= bl_max; sym++) {
+            const int l = (int)BLLEN(sym);
+            if (!l) { BLENT(sym) = 0; continue; }
+            const uint32_t cd = NEXTCODE(l);
+            NEXTCODE(l) = cd + 1;
+            BLENT(sym) = bit_reverse(cd, l) | ((uint32_t)l << 8);
+            const int xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+            opt_len += (long)BLFREQ(sym) * (l + xb);
+        }
+        for (int sym = bl_max + 1; sym < BLELEMS; sym++) BLENT(sym) = 0;
+    }
+    int max_blindex;
+    for (max_blindex = 18; max_blindex >= 3; max_blindex--) {
+        const int o = bl_order(max_blindex);
+        if (o <= bl_max && BLLEN(o) != 0) break;
+    }
+    opt_len += 3 * (max_blindex + 1) + 5 + 5 + 4;
+
+    bl_max_out = bl_max;
+    return max_blindex;
+}
+
 /* blkbase[s] = number of blocks in streams < s (exclusive prefix), blkbase[nstreams] = total */
 __global__ __launch_bounds__(256) void k_block_index(const StreamInfo *__restrict__ sinfo, uint32_t nstreams,
                                                      uint32_t *__restrict__ blkbase)
@@ -302,7 +396,7 @@ __global__ __launch_bounds__(256) void k_block_index(const StreamInfo *__restric
     if (threadIdx.x == 0) blkbase[nstreams] = carry;
 }
 
-template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ sinfo, uint32_t nstreams,
+template <int HT, bool FULL> __global__ __launch_bounds__(HT) void k_huffman(const StreamInfo *__restrict__ sinfo, uint32_t nstreams,
                                                 const uint32_t *__restrict__ blkbase, const uint16_t *__restrict__ blkfreq,
                                                 uint32_t *__restrict__ blkcode, uint32_t *__restrict__ blkhdr,
                                                 BlkMeta *__restrict__ meta,
@@ -456,6 +550,17 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
     opt_len += (long)nmatch;
     static_len += 5L * (long)nmatch;
 
+    if (!FULL) { /* the code-length walk, the bit-length tree and the header bits are k_huffman_hdr's (one wave per tree) */
+        BlkMeta mp;
+        mp.opt_len = (uint32_t)opt_len;
+        mp.static_len = (uint32_t)static_len;
+        mp.hdr_bits = 0;
+        mp.eob = eob;
+        meta[(size_t)s * MAXBLK + b] = mp;
+        HPHASE(7);
+        if (dbg) atomicAdd(&dbg[32], 1ull);
+        return;
+    }
     /* ---------------- bit-length tree (its arrays live in the heap region from here on) ---------------- */
 #pragma unroll
     for (int i = 0; i < BLELEMS; i++) { BLFREQ(i) = 0; BLLEN(i) = 0; }
@@ -487,85 +592,8 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
         BLFREQ(16) = c16; BLFREQ(17) = c17; BLFREQ(18) = c18;
     }
     HPHASE(5);
-    int bn = 0, bl_max = -1;
-    {
-        uint32_t f[BLELEMS];
-#pragma unroll
-        for (int i = 0; i < BLELEMS; i++) f[i] = BLFREQ(i);
-#pragma unroll
-        for (int i = 0; i < BLELEMS; i++)
-            if (f[i]) { bn++; HEAP(bn) = (f[i] << 16) | (uint32_t)i; bl_max = i; }
-    }
-    while (bn < 2) { /* zlib: force at least two codes of non zero frequency */
-        const int node = bl_max < 2 ? ++bl_max : 0;
-        BLFREQ(node) = 1;
-        bn++;
-        HEAP(bn) = (1u << 16) | (uint32_t)node;
-        opt_len--;
-    }
-    uint32_t blmerged = 0;
-    const int bniter = merge_loop<HT>(tm.heap, tid, bn, BLELEMS, &blmerged);
-#pragma unroll
-    for (int i = 0; i < 16; i++) BLCOUNT(i) = 0;
-    overflow = 0;
-    for (int it = bniter - 1; it >= 0; it--) {
-        const uint32_t w = HEAP(bn - it);
-        const int L = (int)((w >> 20) & 31u);
-        for (int side = 1; side >= 0; side--) {
-            const int child = (int)(side ? (w >> 10) & 0x3ffu : w & 0x3ffu);
-            int bits = L + 1;
-            if (bits > 7) { bits = 7; overflow++; }
-            if (child >= BLELEMS) { HEAP(bn - (child - BLELEMS)) |= (uint32_t)bits << 20; continue; }
-            BLLEN(child) = (uint32_t)bits;
-            BLCOUNT(bits) = BLCOUNT(bits) + 1;
-        }
-    }
-    if (overflow > 0) {
-        do {
-            int bits = 6;
-            while (BLCOUNT(bits) == 0) bits--;
-            BLCOUNT(bits) = BLCOUNT(bits) - 1;
-            BLCOUNT(bits + 1) = BLCOUNT(bits + 1) + 2;
-            BLCOUNT(7) = BLCOUNT(7) - 1;
-            overflow -= 2;
-        } while (overflow > 0);
-        int h = 0;
-        for (int bits = 7; bits != 0; bits--) {
-            int cnt = (int)BLCOUNT(bits);
-            while (cnt != 0) {
-                const int m = removed_node<HT>(tm.heap, tid, bn, h);
-                h++;
-                if (m >= BLELEMS) continue;
-                if ((int)BLLEN(m) != bits) BLLEN(m) = (uint32_t)bits;
-                cnt--;
-            }
-        }
-    }
-    {
-        uint32_t c = 0;
-#pragma unroll
-        for (int bits = 1; bits <= 7; bits++) {
-            c = (c + BLCOUNT(bits - 1)) << 1;
-            NEXTCODE(bits) = c;
-        }
-        for (int sym = 0; sym <= bl_max; sym++) {
-            const int l = (int)BLLEN(sym);
-            if (!l) { BLENT(sym) = 0; continue; }
-            const uint32_t cd = NEXTCODE(l);
-            NEXTCODE(l) = cd + 1;
-            BLENT(sym) = bit_reverse(cd, l) | ((uint32_t)l << 8);
-            const int xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
-            opt_len += (long)BLFREQ(sym) * (l + xb);
-        }
-        for (int sym = bl_max + 1; sym < BLELEMS; sym++) BLENT(sym) = 0;
-    }
-    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    int max_blindex;
-    for (max_blindex = 18; max_blindex >= 3; max_blindex--) {
-        const int o = order[max_blindex];
-        if (o <= bl_max && BLLEN(o) != 0) break;
-    }
-    opt_len += 3 * (max_blindex + 1) + 5 + 5 + 4;
+    int bl_max;
+    const int max_blindex = bl_tree_build<HT>(tm, tid, opt_len, bl_max);
 
     HPHASE(6);
     /* ---------------- dynamic header bit string (send_all_trees) ---------------- */
@@ -576,7 +604,7 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
     hw_put(hw, 1u /* max_dcode + 1 - 1 */, 5);
     hw_put(hw, (uint32_t)(max_blindex + 1 - 4), 4);
     for (int r = 0; r <= max_blindex; r++) {
-        const int o = order[r];
+        const int o = bl_order(r);
         hw_put(hw, o <= bl_max ? BLLEN(o) : 0u, 3);
     }
     {
@@ -627,6 +655,198 @@ template <int HT> __global__ __launch_bounds__(HT) void k_huffman(const StreamIn
     HPHASE(7);
     if (dbg) atomicAdd(&dbg[32], 1ull);
 #undef HPHASE
+}
+
+
+/* ======================================================================================
+ * The dynamic header of one block, ONE WAVE PER TREE (k_huffman<HT, false> leaves the code rows and the literal/length part
+ * of the cost): scan_tree, build_bl_tree and send_all_trees (trees.c).  One thread per tree walks the 286 code lengths
+ * symbol by symbol, twice, behind a chain of LDS reads -- 0.27 of the 1.19 M cycles of a tree; here the lanes take the
+ * lengths 64 at a time, find the runs of equal lengths with ballots, and every run's codes follow in closed form:
+ *   a run of R zeros      = floor(R / 138) x REP18(138), then the rest r: 0 nothing, 1..2 literal zeros, 3..10 REP17(r), else REP18(r)
+ *   a run of R lengths L  = c = min(R, 7): c < 4 ? c literals : one literal + REP16(c - 1);   then floor((R - c) / 6) x REP16(6);
+ *                           then the rest r: 0 nothing, 1..2 literals, 3..5 REP16(r)
+ * (zlib's max_count / min_count state only depends on whether the length repeats or is zero, which a run fixes.)  The tiny
+ * bit-length tree itself is built by lane 0 with the same code as the per-thread kernel.
+ * ==================================================================================== */
+struct RunCodes { uint32_t lits_head, rep_head, full, lits_tail, rep_tail; }; /* codes of one run, in the order they are sent */
+__device__ __forceinline__ RunCodes run_codes(uint32_t L, uint32_t R)
+{
+    RunCodes c;
+    if (L == 0u) {
+        c.lits_head = 0; c.rep_head = 0;
+        c.full = R / 138u;
+        const uint32_t r = R % 138u;
+        c.lits_tail = r < 3u ? r : 0u;
+        c.rep_tail = r < 3u ? 0u : r;
+    } else {
+        const uint32_t h = R < 7u ? R : 7u;
+        c.lits_head = h < 4u ? h : 1u;
+        c.rep_head = h < 4u ? 0u : h - 1u;
+        const uint32_t rest = R - h;
+        c.full = rest / 6u;
+        const uint32_t r = rest % 6u;
+        c.lits_tail = r < 3u ? r : 0u;
+        c.rep_tail = r < 3u ? 0u : r;
+    }
+    return c;
+}
+/* OR the low n (<= 16) bits of v into the LDS bit string at bit position pos (bits beyond HDRWORDS dwords are dropped) */
+__device__ __forceinline__ void stage_put(uint32_t *stage, uint32_t pos, uint32_t v, uint32_t n)
+{
+    if (n == 0u) return;
+    const uint32_t w = pos >> 5, sh = pos & 31u;
+    if (w < (uint32_t)HDRWORDS) atomicOr(&stage[w], v << sh);
+    if (sh + n > 32u && w + 1u < (uint32_t)HDRWORDS) atomicOr(&stage[w + 1u], v >> (32u - sh));
+}
+
+__global__ __launch_bounds__(64) void k_huffman_hdr(const StreamInfo *__restrict__ sinfo, uint32_t nstreams,
+                                                    const uint32_t *__restrict__ blkbase, const uint32_t *__restrict__ blkcode,
+                                                    uint32_t *__restrict__ blkhdr, BlkMeta *__restrict__ meta)
+{
+    constexpr int HT = 1; /* (the macros below address the tree of "thread" 0) */
+    __shared__ TreeMem<HT> tm;
+    __shared__ uint32_t stage[HDRWORDS];
+    __shared__ int s_maxbl, s_blmax;
+    __shared__ long s_opt;
+    const int tid = 0;
+    const int lane = threadIdx.x;
+    const uint32_t job = blockIdx.x;
+    if (job >= blkbase[nstreams]) return;
+    uint32_t lo = 0, hi = nstreams - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (blkbase[mid] <= job) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t s = lo, b = job - blkbase[lo];
+    const uint32_t *code = blkcode + ((size_t)s * MAXBLK + b) * HROW;
+    /* the lanes' lengths: symbol 64 k + lane */
+    uint32_t l[5];
+    int maxc = -1;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int sym = 64 * k + lane;
+        l[k] = sym < LELEMS ? code[sym] >> 16 : 0u;
+        if (l[k]) maxc = sym;
+    }
+    maxc = wave_max_i(maxc); /* >= 256: END_BLOCK always has a code */
+    for (int i = lane; i < HDRWORDS; i += 64) stage[i] = 0;
+    if (lane < BLELEMS) { BLFREQ(lane) = 0; BLLEN(lane) = 0; }
+    __builtin_amdgcn_wave_barrier();
+    /* run starts (a sentinel start behind the last symbol ends the last run) */
+    unsigned long long M[5];
+    bool st[5];
+    uint32_t carry_len = 0xffffffffu; /* length of symbol 64 k - 1 */
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int sym = 64 * k + lane;
+        uint32_t prev = (uint32_t)__shfl_up((int)l[k], 1);
+        if (lane == 0) prev = carry_len;
+        carry_len = (uint32_t)__shfl((int)l[k], 63);
+        st[k] = sym <= maxc + 1 && (sym == 0 || sym == maxc + 1 || l[k] != prev);
+        M[k] = __ballot(st[k]);
+    }
+    /* every run: its length, then what it contributes to the bit-length symbols' counts */
+    uint32_t R[5];
+    uint32_t n16 = 0, n17 = 0, n18 = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int sym = 64 * k + lane;
+        R[k] = 0;
+        if (st[k] && sym <= maxc) {
+            int next = -1;
+            const unsigned long long above = lane == 63 ? 0ull : (M[k] & (~0ull << (lane + 1)));
+            if (above) next = 64 * k + ctz64(above);
+#pragma unroll
+            for (int k2 = 1; k2 < 5; k2++)
+                if (next < 0 && k + k2 < 5 && M[(k + k2) % 5]) next = 64 * (k + k2) + ctz64(M[(k + k2) % 5]);
+            R[k] = (uint32_t)(next - sym);
+            const RunCodes c = run_codes(l[k], R[k]);
+            const uint32_t nlit = c.lits_head + c.lits_tail;
+            if (nlit) atomicAdd(&BLFREQ(l[k]), nlit);
+            const uint32_t reps = (c.rep_head ? 1u : 0u) + c.full + (c.rep_tail ? 1u : 0u);
+            if (l[k]) n16 += reps;
+            else { n18 += c.full + (c.rep_tail > 10u ? 1u : 0u); n17 += (c.rep_tail >= 3u && c.rep_tail <= 10u) ? 1u : 0u; }
+        }
+    }
+    n16 = wave_sum_u(n16); n17 = wave_sum_u(n17); n18 = wave_sum_u(n18);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        BLFREQ(1) += 2u; /* the distance tree's lengths {1, 1}: a run of two, two literals */
+        BLFREQ(16) = n16; BLFREQ(17) = n17; BLFREQ(18) = n18;
+        const BlkMeta mp = meta[(size_t)s * MAXBLK + b];
+        long opt = (long)mp.opt_len;
+        int bl_max;
+        s_maxbl = bl_tree_build<HT>(tm, tid, opt, bl_max);
+        s_blmax = bl_max;
+        s_opt = opt;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int max_blindex = s_maxbl, bl_max = s_blmax;
+    /* ---- the header bit string ---- */
+    const uint32_t pre_bits = 14u + 3u * (uint32_t)(max_blindex + 1);
+    if (lane == 0) {
+        stage_put(stage, 0, (uint32_t)(maxc + 1 - 257), 5);
+        stage_put(stage, 5, 1u /* max_dcode + 1 - 1 */, 5);
+        stage_put(stage, 10, (uint32_t)(max_blindex + 1 - 4), 4);
+    }
+    if (lane <= max_blindex) {
+        const int o = bl_order(lane);
+        stage_put(stage, 14u + 3u * (uint32_t)lane, o <= bl_max ? BLLEN(o) : 0u, 3);
+    }
+    const uint32_t e16 = BLENT(16), e17 = BLENT(17), e18 = BLENT(18), e1 = BLENT(1);
+    uint32_t base = pre_bits;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        uint32_t bits = 0;
+        RunCodes c;
+        c.lits_head = c.rep_head = c.full = c.lits_tail = c.rep_tail = 0;
+        uint32_t el = 0;
+        if (R[k]) {
+            c = run_codes(l[k], R[k]);
+            el = BLENT(l[k]);
+            const uint32_t ll = el >> 8;
+            const uint32_t er = l[k] ? e16 : 0u; /* (zero runs: the tail chooses 17 or 18) */
+            bits = (c.lits_head + c.lits_tail) * ll;
+            if (l[k]) bits += ((c.rep_head ? 1u : 0u) + c.full + (c.rep_tail ? 1u : 0u)) * ((er >> 8) + 2u);
+            else bits += c.full * ((e18 >> 8) + 7u) + (c.rep_tail > 10u ? (e18 >> 8) + 7u : (c.rep_tail >= 3u ? (e17 >> 8) + 3u : 0u));
+        }
+        uint32_t tot;
+        uint32_t pos = base + wave_excl_sum(bits, &tot);
+        base += tot;
+        if (R[k]) {
+            const uint32_t lc = el & 0xffu, ll = el >> 8;
+            for (uint32_t i = 0; i < c.lits_head; i++) { stage_put(stage, pos, lc, ll); pos += ll; }
+            if (l[k]) {
+                const uint32_t rc = e16 & 0xffu, rl = e16 >> 8;
+                if (c.rep_head) { stage_put(stage, pos, rc | ((c.rep_head - 3u) << rl), rl + 2u); pos += rl + 2u; }
+                for (uint32_t i = 0; i < c.full; i++) { stage_put(stage, pos, rc | (3u << rl), rl + 2u); pos += rl + 2u; }
+                for (uint32_t i = 0; i < c.lits_tail; i++) { stage_put(stage, pos, lc, ll); pos += ll; }
+                if (c.rep_tail) { stage_put(stage, pos, rc | ((c.rep_tail - 3u) << rl), rl + 2u); pos += rl + 2u; }
+            } else {
+                const uint32_t r8c = e18 & 0xffu, r8l = e18 >> 8, r7c = e17 & 0xffu, r7l = e17 >> 8;
+                for (uint32_t i = 0; i < c.full; i++) { stage_put(stage, pos, r8c | (127u << r8l), r8l + 7u); pos += r8l + 7u; }
+                for (uint32_t i = 0; i < c.lits_tail; i++) { stage_put(stage, pos, lc, ll); pos += ll; }
+                if (c.rep_tail > 10u) { stage_put(stage, pos, r8c | ((c.rep_tail - 11u) << r8l), r8l + 7u); pos += r8l + 7u; }
+                else if (c.rep_tail >= 3u) { stage_put(stage, pos, r7c | ((c.rep_tail - 3u) << r7l), r7l + 3u); pos += r7l + 3u; }
+            }
+        }
+    }
+    if (lane == 0) { /* the distance tree's two lengths */
+        stage_put(stage, base, e1 & 0xffu, e1 >> 8);
+        stage_put(stage, base + (e1 >> 8), e1 & 0xffu, e1 >> 8);
+    }
+    const uint32_t total_bits = base + 2u * (e1 >> 8);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t *dst = blkhdr + ((size_t)s * MAXBLK + b) * HDRWORDS;
+    const uint32_t nwords = (total_bits + 31u) >> 5;
+    for (uint32_t i = lane; i < nwords && i < (uint32_t)HDRWORDS; i += 64) dst[i] = stage[i];
+    if (lane == 0) {
+        BlkMeta m = meta[(size_t)s * MAXBLK + b];
+        m.opt_len = (uint32_t)s_opt;
+        m.hdr_bits = total_bits;
+        meta[(size_t)s * MAXBLK + b] = m;
+    }
 }
 
 } /* namespace mrcz */
