@@ -163,7 +163,7 @@ static int g_ses_busy[MAXDEV][SESSIONS_PER_DEV];
 static pthread_mutex_t g_ses_mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_ses_cv = PTHREAD_COND_INITIALIZER;
 
-__attribute__((unused)) static void session_release(void *p)
+static void session_release(void *p)
 {
     session_t *s = (session_t *)p;
     if (!s || !s->ndev) return;
@@ -183,6 +183,15 @@ __attribute__((unused)) static void session_release(void *p)
     }
     memset(s, 0, sizeof(*s));
 }
+/* orderly exit (a host program that links the library and returns from main): give the pinned rings and device buffers back */
+static void sessions_release_all(void)
+{
+    for (int d = 0; d < MAXDEV; d++)
+        for (int i = 0; i < SESSIONS_PER_DEV; i++) session_release(&g_ses[d][i]);
+}
+static pthread_once_t g_ses_once = PTHREAD_ONCE_INIT;
+static void sessions_register_exit(void) { atexit(sessions_release_all); }
+
 static void session_put(session_t *s)
 {
     pthread_mutex_lock(&g_ses_mu);
@@ -205,6 +214,7 @@ static int thread_ndev(void)
 static session_t *session_get(uint64_t a_bytes, uint64_t b_bytes, int nd)
 {
     if (t_device < 0 || t_device >= MAXDEV) die("device index out of range", NULL);
+    pthread_once(&g_ses_once, sessions_register_exit);
     session_t *s = NULL;
     pthread_mutex_lock(&g_ses_mu);
     while (!s) {
