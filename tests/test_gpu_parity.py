@@ -140,6 +140,33 @@ def test_tile_of_long_codes_exceeds_the_emit_staging_buffer(codec, oracle):
     _roundtrip(codec, oracle, np.concatenate([common(12000), rare, common(40000), rare, common(300000)]), 0)
 
 
+def test_huffman_header_paths_agree(monkeypatch):
+    # the dynamic headers come from k_huffman_hdr (one wave per tree, runs of equal lengths in closed form) by default and from the
+    # per-thread walk of k_huffman with MRCZ_HUFF_SPLIT=0: the two must write the same bytes on any input
+    import torch
+    from datacompressionfloat_amd import MrcZipCodec
+    monkeypatch.setenv("MRCZ_HUFF_SPLIT", "0")
+    mono = MrcZipCodec(0, max_batch_chunks=4)
+    monkeypatch.setenv("MRCZ_HUFF_SPLIT", "1")
+    split = MrcZipCodec(0, max_batch_chunks=4)
+    rng = np.random.default_rng(2026)
+    for case in range(18):
+        n = int(rng.integers(1, 1_500_000))
+        kind = case % 6
+        if kind == 0: w = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        elif kind == 1: w = rng.normal(10, 3, n).astype(np.float32).view(np.uint32)
+        elif kind == 2: w = rng.poisson(8.0, n).astype(np.float32).view(np.uint32)
+        elif kind == 3: w = (rng.integers(0, 4, n, dtype=np.uint64) ** 3).astype(np.uint32) * np.uint32(0x01010101)
+        elif kind == 4: w = np.repeat(rng.integers(0, 2**32, n // 97 + 1, dtype=np.uint64).astype(np.uint32), 97)[:n]
+        else: w = rng.geometric(0.02, n).astype(np.uint32) | (rng.integers(0, 3, n, dtype=np.uint64).astype(np.uint32) << 16)
+        bits = int(rng.choice([0, 4, 8, 12, 16, 20, 23, 28, 32]))
+        t = torch.from_numpy(np.ascontiguousarray(w).view(np.int32)).cuda()
+        a, _ = mono.compress_device(t, bits, 0)
+        b, _ = split.compress_device(t, bits, 0)
+        assert torch.equal(a, b), (case, kind, n, bits, a.numel(), b.numel())
+    mono.close(); split.close()
+
+
 def test_planes_that_begin_with_stored_blocks(codec, oracle):
     # noise, then constants: the stream of every plane starts with STORED blocks and goes on with coded ones (see tests/test_sim.py)
     rng = np.random.default_rng(11)
