@@ -35,6 +35,7 @@ struct mrcz_ctx {
     hipEvent_t ev_start, ev_cont, ev_done[MAX_LANES];
     hipEvent_t ev_stream[MAX_LANES]; /* lane l's summary + histogram passes are done */
     uint32_t huff_split;           /* the blocks' dynamic headers by k_huffman_hdr, one wave per tree (MRCZ_HUFF_SPLIT=0: inside k_huffman, one thread per tree) */
+    uint32_t validate_wave, validate_grid; /* candidate headers: one wave each (MRCZ_VALIDATE_WAVE=0: one lane each) */
     uint32_t use_hint;             /* block decoder: size the pieces of a window by where the block probably ends (MRCZ_HINT=0: off) */
     uint32_t split_pct;            /* two lanes: share of a batch's chunks (per cent) the first lane takes; MRCZ_SPLIT overrides it */
     int stagger;                   /* lanes start one after the other (each once the previous one's streaming passes are done), so that
@@ -166,6 +167,10 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->split_pct = 55; /* (measured: 50 -> 2.58 ms, 55 -> 2.56, 60 -> 2.60; three lanes, even or uneven, 2.8-2.9) */
     ctx->use_hint = 1;
     ctx->huff_split = 1;
+    ctx->validate_wave = 1;
+    ctx->validate_grid = 4096;
+    if (const char *ev = getenv("MRCZ_VALIDATE_WAVE")) ctx->validate_wave = atoi(ev) ? 1u : 0u;
+    if (const char *ev = getenv("MRCZ_VALIDATE_GRID")) { const int v = atoi(ev); if (v >= 1 && v <= 65535) ctx->validate_grid = (uint32_t)v; }
     if (const char *ev = getenv("MRCZ_HUFF_SPLIT")) ctx->huff_split = atoi(ev) ? 1u : 0u;
     if (const char *ev = getenv("MRCZ_HINT")) ctx->use_hint = atoi(ev) ? 1u : 0u;
     if (const char *ev = getenv("MRCZ_SPLIT")) { const int v = atoi(ev); if (v >= 5 && v <= 95) ctx->split_pct = (uint32_t)v; }
@@ -551,14 +556,19 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
         const uint32_t ns = 4 * nb;
         HIPCHK(hipMemsetAsync(ctx->ncand, 0, ns * sizeof(uint32_t), ctx->stream), "memset ncand");
         HIPCHK(hipMemsetAsync(ctx->njobs, 0, (4 + RAW_SEGS) * sizeof(uint32_t), ctx->stream), "memset njobs");
-        if (ctx->phase_profile == 2) HIPCHK(hipMemsetAsync(ctx->dbgphase, 0, (size_t)ns * 40 * sizeof(unsigned long long), ctx->stream), "memset dbg");
+        if (ctx->phase_profile == 2 || ctx->phase_profile == 4) HIPCHK(hipMemsetAsync(ctx->dbgphase, 0, (size_t)ns * 40 * sizeof(unsigned long long), ctx->stream), "memset dbg");
         if (ctx->phase_profile != 1) { /* (1 = profiling vehicle: every stream through the sequential-chain kernel with phase counters) */
             /* block-parallel path: find block starts, size every candidate block, close the chains, write */
             ctx->calltag = ctx->calltag * 0x01000193u + 0x9e3779b9u;
             LAUNCH("k_scan_candidates", k_scan_candidates, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(64), rec, len,
                    ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 4, ctx->rawcap);
-            LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 4,
-                   ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag);
+            if (ctx->validate_wave)
+                LAUNCH("k_validate_candidates", k_validate_wave, dim3(ctx->validate_grid), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 4,
+                       ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag);
+            else
+                LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 4,
+                       ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag,
+                       ctx->phase_profile == 4 ? ctx->dbgphase + (size_t)ns * 8 : (unsigned long long *)NULL);
             LAUNCH("k_cand_index", k_cand_index, dim3(1), dim3(256), ctx->ncand, ctx->dstreams, ns, ctx->candbase, ctx->jobord);
             /* fixed grid: the workgroups pull candidate numbers from ctx->njobs[0] until it passes candbase[ns] (no read-back) */
             LAUNCH("k_blk_count", k_blk_count, dim3(ctx->blk_grid), dim3(PT), rec, len, ctx->dstreams, ns, ctx->candbase, ctx->jobord,
@@ -566,7 +576,7 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
                      ctx->phase_profile == 2 ? ctx->dbgphase : (unsigned long long *)NULL, ctx->use_hint);
         }
         LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->segs, ctx->nseg, ctx->segidx,
-               ctx->fallback, ctx->phase_profile == 1 ? 1u : 0u);
+               ctx->fallback, ctx->phase_profile == 1 ? 1u : 0u, ctx->phase_profile == 4 ? ctx->dbgphase : (unsigned long long *)NULL);
         LAUNCH("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
                  ctx->fallback, ctx->phase_profile == 1 ? ctx->dbgphase : (unsigned long long *)NULL);
         LAUNCH("k_inflate_seq", k_inflate, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);

@@ -1372,8 +1372,10 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
                                                             const DecStream *__restrict__ ds, const uint2 *__restrict__ rawlist,
                                                             const uint32_t *__restrict__ nraw, uint32_t rawcap,
                                                             Cand *__restrict__ cands, uint32_t *__restrict__ ncand,
-                                                            HdrCache *__restrict__ hdrs, uint32_t calltag)
+                                                            HdrCache *__restrict__ hdrs, uint32_t calltag,
+                                                            unsigned long long *__restrict__ dbg /* NULL, or developer stamps: 8 per workgroup for the first 64 */)
 {
+#define VSTAMP(i) do { if (dbg && blockIdx.x < 64u && threadIdx.x == 0) dbg[blockIdx.x * 8u + (i)] = (unsigned long long)clock64(); } while (0)
     /* One candidate per lane.  A header is ~300 code-length symbols decoded one after the other; reading each from
      * global memory made this kernel one long chain of dependent HBM/L2 round trips.  Each lane first copies its
      * candidate's 256 bytes into its own LDS column (64 independent loads), then parses from there. */
@@ -1399,6 +1401,7 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
     }
     __syncthreads();
     const uint32_t total = segbase[RAW_SEGS];
+    VSTAMP(0);
     for (uint32_t j = blockIdx.x * 64 + threadIdx.x; j < total; j += gridDim.x * 64) {
         uint32_t g = 0;
         for (uint32_t stp = RAW_SEGS / 2; stp; stp >>= 1) if (segbase[g + stp] <= j) g += stp;
@@ -1418,8 +1421,10 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
             }
             hw[w * 64 + lane] = v;
         }
+        VSTAMP(1);
 #pragma unroll
         for (uint32_t k = 0; k < VROW - 1u; k++) vlens32[VROW * (uint32_t)lane + k] = 0;
+        VSTAMP(2);
         /* n <= 25 bits at global bit position g: from the lane's LDS column when staged, else from memory */
         auto gbits = [&](const uint8_t *, uint64_t, uint64_t g, int n) -> uint32_t {
             const uint64_t q = g - (wbase << 5);
@@ -1480,6 +1485,7 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
                 }
             }
         }
+        VSTAMP(3);
         const uint32_t total_l = nlen + ndist;
         uint32_t idx = 0, kraft = 0, prev = 0, eoblen = 0;
         /* The symbols: a 64-bit bit buffer refilled from the lane's LDS column (the refill address only depends on how
@@ -1496,33 +1502,48 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
         } else ok = false; /* (cannot happen: the code-length code ends inside the first four words) */
         const uint32_t pay_end = paybits - p; /* bits from the candidate's start to the end of the payload */
         const uint32_t used0 = (uint32_t)(g0 - (wbase << 5));
-        while (ok && idx < total_l) {
-            if (nb < 32) {
-                const uint32_t w = wi < (uint32_t)VH_WORDS ? hw[wi * 64 + lane]
-                                                            : (uint32_t)mrcz::gbits(rec, reclen, (wbase + wi) << 5, 16) | ((uint32_t)mrcz::gbits(rec, reclen, ((wbase + wi) << 5) + 16, 16) << 16);
-                buf |= (unsigned long long)w << nb;
-                nb += 32;
-                wi++;
-            }
-            if (used - used0 + 14u > pay_end) { ok = false; break; }
+        /* Straight-line steps: a wave is alone on its SIMD here, so what a step costs is its instruction count, and with one
+         * candidate per lane every branch a lane takes is paid by all 64.  All state changes are selects on `go`; the loop
+         * runs until no lane is parsing.  The lengths of a step go out as six byte stores (a non-zero length repeats at most
+         * six times; the bytes behind the run are still zero and are written as zero). */
+        bool act = ok;
+        for (;;) {
+            act = act && idx < total_l;
+            if (!__any(act)) break;
+            const bool need = nb < 32;
+            uint32_t w = hw[(wi < (uint32_t)VH_WORDS ? wi : (uint32_t)VH_WORDS - 1u) * 64 + lane];
+            if (act && need && wi >= (uint32_t)VH_WORDS) /* a header longer than the staged 256 bytes: from memory */
+                w = (uint32_t)mrcz::gbits(rec, reclen, (wbase + wi) << 5, 16) | ((uint32_t)mrcz::gbits(rec, reclen, ((wbase + wi) << 5) + 16, 16) << 16);
+            buf |= need ? ((unsigned long long)w << nb) : 0ull;
+            nb += need ? 32 : 0;
+            wi += need ? 1u : 0u;
+            bool go = act && used - used0 + 14u <= pay_end;
             const uint32_t v = (uint32_t)buf & 0x3fffu;
             const uint32_t e = vlut[(v & 127u) * 64u + (uint32_t)lane];
             const uint32_t l = e >> 5, sym = e & 31u;
-            uint32_t rep = 1, val = sym, take = l;
-            if (sym == 16u) { if (idx == 0) { ok = false; break; } val = prev; rep = 3u + ((v >> l) & 3u); take += 2; }
-            else if (sym == 17u) { val = 0; rep = 3u + ((v >> l) & 7u); take += 3; }
-            else if (sym == 18u) { val = 0; rep = 11u + ((v >> l) & 127u); take += 7; }
-            buf >>= take; nb -= (int)take; used += take;
-            if (idx + rep > total_l) { ok = false; break; }
+            const bool is16 = sym == 16u, is17 = sym == 17u, is18 = sym == 18u;
+            const uint32_t nex = is18 ? 7u : is17 ? 3u : is16 ? 2u : 0u;
+            const uint32_t rep = sym < 16u ? 1u : (is18 ? 11u : 3u) + ((v >> l) & ((1u << nex) - 1u));
+            const uint32_t val = sym < 16u ? sym : is16 ? prev : 0u;
+            const uint32_t take = l + nex;
+            go = go && !(is16 && idx == 0u) && idx + rep <= total_l;
             /* the lengths at [idx, idx + rep) that belong to the literal/length code */
             const uint32_t lo = idx < nlen ? idx : nlen, hi = idx + rep < nlen ? idx + rep : nlen;
-            if (val) kraft += (hi - lo) * (32768u >> val);
-            if (lo <= 256u && 256u < hi) eoblen = val;
-            if (kraft > 32768u) { ok = false; break; } /* over-subscribed: no code */
-            if (val) for (uint32_t k = 0; k < rep; k++) vrow[idx + k] = (uint8_t)val; /* <= 6 */
-            idx += rep;
-            prev = val;
+            const uint32_t kr = kraft + (val ? (hi - lo) * (32768u >> val) : 0u);
+            go = go && kr <= 32768u; /* over-subscribed: no code */
+#pragma unroll
+            for (uint32_t k = 0; k < 6u; k++) vrow[idx + k] = (uint8_t)((go && k < rep) ? val : 0u);
+            kraft = go ? kr : kraft;
+            eoblen = (go && lo <= 256u && 256u < hi) ? val : eoblen;
+            buf >>= go ? take : 0u;
+            nb -= go ? (int)take : 0;
+            used += go ? take : 0u;
+            idx += go ? rep : 0u;
+            prev = go ? val : prev;
+            ok = ok && (go || !act);
+            act = go;
         }
+        VSTAMP(4);
         if (ok && kraft == 32768u && eoblen != 0u) {
             const uint32_t i = atomicAdd(&ncand[s], 1u);
             if (i < (uint32_t)MAXCAND) {
@@ -1533,6 +1554,171 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
                 hc->bfinal = 0; hc->nlen = nlen; hc->ndist = ndist;
                 hc->cur_after = p + (used - used0);
                 hc->valid = hdr_tag(calltag, p);
+            }
+        }
+        VSTAMP(5);
+    }
+    VSTAMP(6);
+#undef VSTAMP
+}
+
+/* D1b, one WAVE per survivor.  The per-lane version above is as long as its slowest lane: ~300 code-length symbols one
+ * after the other at ~800 clocks each (a wave alone on its SIMD issues an instruction every five clocks or so), 150 us
+ * per call however few candidates there are.  Here the 64 lanes share one header:
+ *   - the header's 256 bytes are one coalesced load; the code-length code's table is filled by its 19 symbols at once;
+ *   - a round looks at 64 consecutive bit positions: every lane decodes the symbol that WOULD start at its bit, then the
+ *     positions where symbols really start are found by hopping from symbol to symbol with scalar lane reads (two per
+ *     symbol), and everything else -- run values behind "repeat previous", positions in the length array by a prefix sum,
+ *     the Kraft sum, the stores -- is done by the marked lanes together;
+ *   - false candidates decode noise, whose zero runs reach HLIT + HDIST lengths within two or three rounds.
+ * The accepted candidates and their HdrCache rows are the same as the per-lane kernel's (same tests), in another order. */
+__global__ __launch_bounds__(64) void k_validate_wave(const uint8_t *__restrict__ rec, uint64_t reclen,
+                                                      const DecStream *__restrict__ ds, const uint2 *__restrict__ rawlist,
+                                                      const uint32_t *__restrict__ nraw, uint32_t rawcap,
+                                                      Cand *__restrict__ cands, uint32_t *__restrict__ ncand,
+                                                      HdrCache *__restrict__ hdrs, uint32_t calltag)
+{
+    __shared__ uint32_t hw[VH_WORDS + 2];
+    __shared__ uint8_t tab[128];
+    __shared__ uint32_t lens32[84];
+    __shared__ uint8_t cl[32];
+    __shared__ uint32_t segbase[RAW_SEGS + 1];
+    __shared__ uint32_t eob_s;
+    const int lane = threadIdx.x;
+    uint8_t *lens = reinterpret_cast<uint8_t *>(lens32);
+    const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
+    const uint64_t nrec32 = reclen >> 2;
+    const uint32_t segcap = rawcap / RAW_SEGS;
+    if (lane == 0) {
+        uint32_t acc = 0;
+        for (uint32_t g = 0; g < RAW_SEGS; g++) { segbase[g] = acc; const uint32_t c = nraw[g]; acc += c < segcap ? c : segcap; }
+        segbase[RAW_SEGS] = acc;
+    }
+    __syncthreads();
+    const uint32_t total = segbase[RAW_SEGS];
+    /* hw[0 .. VH_WORDS + 1] = the record words from word `wb` on */
+    auto stage = [&](uint64_t wb) {
+        for (uint32_t w = (uint32_t)lane; w < (uint32_t)VH_WORDS + 2u; w += 64u) {
+            const uint64_t wi = wb + w;
+            uint32_t v = 0;
+            if (wi < nrec32) v = rec32[wi];
+            else if (wi * 4 < reclen) for (uint64_t k = wi * 4; k < reclen; k++) v |= (uint32_t)rec[k] << (8 * (k - wi * 4)); /* ragged tail */
+            hw[w] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    /* >= 32 bits from bit `bp` of the staged words (bp < 32 * VH_WORDS) */
+    auto peek = [&](uint32_t bp) -> uint32_t {
+        const uint32_t i = bp >> 5;
+        const unsigned long long v = (unsigned long long)hw[i] | ((unsigned long long)hw[i + 1u] << 32);
+        return (uint32_t)(v >> (bp & 31u));
+    };
+    for (uint32_t j = blockIdx.x; j < total; j += gridDim.x) {
+        uint32_t g = 0;
+        for (uint32_t stp = RAW_SEGS / 2; stp; stp >>= 1) if (segbase[g + stp] <= j) g += stp;
+        const uint2 rl = rawlist[(size_t)g * segcap + (j - segbase[g])];
+        const uint32_t s = rl.x, p = rl.y;
+        const DecStream d = ds[s];
+        const uint64_t g0 = d.payoff * 8ull + p;
+        const uint32_t pay_end = d.paylen * 8u - p; /* bits from the candidate's start to the end of the payload */
+        const uint64_t wb0 = g0 >> 5;
+        uint64_t wb = wb0;
+        const uint32_t cur0 = (uint32_t)g0 & 31u;
+        __builtin_amdgcn_wave_barrier(); /* the previous candidate's readers of hw / tab / lens are done */
+        stage(wb);
+        for (uint32_t k = (uint32_t)lane; k < 84u; k += 64u) lens32[k] = 0;
+        if (lane < 32) cl[lane] = 0;
+        if (lane == 0) eob_s = 0;
+        const uint32_t hdr = peek(cur0);
+        const uint32_t nlen = ((hdr >> 3) & 31u) + 257u, ndist = ((hdr >> 8) & 31u) + 1u, ncode = ((hdr >> 13) & 15u) + 4u;
+        const uint32_t total_l = nlen + ndist;
+        bool ok = nlen <= 286u && ndist <= 30u; /* (uniform) */
+        __builtin_amdgcn_wave_barrier();
+        /* code-length code: lane i < ncode reads the i-th 3-bit length, which belongs to symbol k_bl_order(i) */
+        if ((uint32_t)lane < ncode) cl[k_bl_order(lane)] = (uint8_t)(peek(cur0 + 17u + 3u * (uint32_t)lane) & 7u);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t mylen = lane < 19 ? (uint32_t)cl[lane] : 0u;
+        uint32_t code = 0, next = 0, blkraft = 0, mycode = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 7u; l++) {
+            const unsigned long long same = __ballot(mylen == l);
+            if (mylen == l) mycode = next + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            const uint32_t cnt = (uint32_t)__popcll(same);
+            blkraft += cnt << (7u - l);
+            next = (next + cnt) << 1;
+        }
+        (void)code;
+        ok = ok && blkraft == 128u; /* complete code: every table entry gets written */
+        if (ok && mylen) {
+            const uint32_t r = __brev(mycode) >> (32u - mylen);
+            for (uint32_t k = r; k < 128u; k += 1u << mylen) tab[k] = (uint8_t)((uint32_t)lane | (mylen << 5));
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t cur = cur0 + 17u + 3u * ncode; /* bit inside the staged words where the next symbol starts (uniform) */
+        uint32_t idx = 0, prevlen = 0;            /* lengths decoded so far, the last one (uniform) */
+        uint32_t kr = 0;                           /* this lane's share of the literal/length code's Kraft sum */
+        while (ok && idx < total_l) {
+            if (cur + 64u + 14u + 32u > 32u * (uint32_t)VH_WORDS) { /* a long header: move the staged window up */
+                wb += cur >> 5;
+                cur &= 31u;
+                __builtin_amdgcn_wave_barrier();
+                stage(wb);
+            }
+            /* the symbol that would start at this lane's bit */
+            const uint32_t v = peek(cur + (uint32_t)lane) & 0x3fffu;
+            const uint32_t e = tab[v & 127u];
+            const uint32_t l = e >> 5, sym = e & 31u;
+            const bool is16 = sym == 16u, is17 = sym == 17u, is18 = sym == 18u;
+            const uint32_t nex = is18 ? 7u : is17 ? 3u : is16 ? 2u : 0u;
+            const uint32_t rep = sym < 16u ? 1u : (is18 ? 11u : 3u) + ((v >> l) & ((1u << nex) - 1u));
+            const uint32_t take = l + nex;
+            /* where symbols really start: hop from one to the next (scalar), until the window or the lengths end */
+            unsigned long long starts = 0;
+            uint32_t b = 0, idx_end = idx;
+            while (b < 64u && idx_end < total_l) {
+                starts |= 1ull << b;
+                idx_end += (uint32_t)__builtin_amdgcn_readlane((int)rep, (int)b);
+                b += (uint32_t)__builtin_amdgcn_readlane((int)take, (int)b);
+            }
+            if (idx_end > total_l) { ok = false; break; } /* the last run overshoots */
+            const bool on = (starts >> lane) & 1ull;
+            uint32_t tot;
+            const uint32_t myidx = idx + wave_excl_sum(on ? rep : 0u, &tot);
+            /* "repeat previous": the value of the nearest symbol before it that is not one, or the last length of the round before */
+            const unsigned long long base = __ballot(on && !is16);
+            const unsigned long long below = base & ((1ull << lane) - 1ull);
+            const uint32_t basev = sym < 16u ? sym : 0u;
+            const uint32_t from = (uint32_t)__shfl((int)basev, below ? 63 - __clzll((long long)below) : 0);
+            const uint32_t val = !is16 ? basev : (below ? from : prevlen);
+            if (__ballot(on && is16 && myidx == 0u)) { ok = false; break; } /* nothing to repeat */
+            prevlen = (uint32_t)__shfl((int)val, 63 - __clzll((long long)starts));
+            if (on && val) {
+                const uint32_t lo = myidx < nlen ? myidx : nlen, hi = myidx + rep < nlen ? myidx + rep : nlen;
+                kr += (hi - lo) * (32768u >> val);
+                if (lo <= 256u && 256u < hi) eob_s = val;
+                for (uint32_t k = 0; k < rep; k++) lens[myidx + k] = (uint8_t)val; /* <= 6 */
+            }
+            idx = idx_end;
+            cur += b;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t kraft;
+        (void)wave_excl_sum(kr, &kraft);
+        const uint32_t used = (uint32_t)((wb - wb0) << 5) + cur - cur0;
+        if (ok && idx == total_l && kraft == 32768u && eob_s != 0u && used <= pay_end) {
+            uint32_t i = 0;
+            if (lane == 0) i = atomicAdd(&ncand[s], 1u);
+            i = (uint32_t)__shfl((int)i, 0);
+            if (i < (uint32_t)MAXCAND) {
+                HdrCache *hc = hdrs + ((size_t)s * MAXCAND + i);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(hc->lens);
+                for (uint32_t k = (uint32_t)lane; k < (total_l + 3u) / 4u; k += 64u) dst[k] = lens32[k]; /* (lengths behind total_l are zero) */
+                if (lane == 0) {
+                    Cand cnd; cnd.bit = p; cnd.end = 0; cnd.nout = 0; cnd.info = 0; cands[(size_t)s * MAXCAND + i] = cnd;
+                    hc->bfinal = 0; hc->nlen = nlen; hc->ndist = ndist;
+                    hc->cur_after = p + used;
+                    hc->valid = hdr_tag(calltag, p);
+                }
             }
         }
     }
@@ -1673,26 +1859,34 @@ struct Seg {
 };
 constexpr uint32_t CH_SLOTS = 2048, CH_EMPTY = 0xffffffffu; /* hash of candidate start bits: <= MAXCAND keys */
 constexpr uint32_t CH_STORED = 0xffffu;                      /* block list entry: a stored block (no candidate) */
+constexpr uint32_t CH_JUMP = 512, CH_LEVELS = 9;             /* pointer jumping over the candidates of a stream: 2^CH_LEVELS = CH_JUMP */
+constexpr uint32_t CH_LONG = 32;                             /* long windows whose tile index the wave fills together */
+constexpr uint32_t CI_BADSPAN = 8u;                          /* c_rec info bit: the candidate does not end behind its start */
 
 /* D3: per stream, follow the chain of blocks from bit 0 (a candidate is accepted only where the previous block ended,
  * stored blocks are sized on the spot) and lay the accepted blocks' windows out as segments; segidx[t] = the segment
  * that holds the first position of merge tile t.  One wave per stream, two phases:
- *   1. the walk itself, strictly serial but in LDS only: candidate start bits in a hash, the fields a step depends on
- *      (end, bytes, info) in LDS arrays, so one step is two LDS round trips; it leaves the list of accepted blocks;
+ *   1. the walk itself, strictly serial but in LDS only: candidate start bits in a hash, every candidate's successor
+ *      looked up beforehand (all candidates at once), so one step is one 16-byte LDS read; it leaves the list of accepted
+ *      blocks;
  *   2. the blocks' windows -> segments, one block per lane (the window records come from global memory, 64 independent
  *      loads at a time), segment numbers by a wave prefix sum. */
 __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, uint64_t reclen,
                                               const DecStream *__restrict__ ds, const Cand *__restrict__ cands,
                                               const uint32_t *__restrict__ ncand, Seg *__restrict__ segs,
                                               uint32_t *__restrict__ nseg, uint16_t *__restrict__ segidx,
-                                              uint32_t *__restrict__ fallback, uint32_t force_fallback)
+                                              uint32_t *__restrict__ fallback, uint32_t force_fallback,
+                                              unsigned long long *__restrict__ dbg /* NULL, or developer stamps: 8 per stream */)
 {
+#define CSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8u + (i)] = (unsigned long long)clock64(); } while (0)
+    CSTAMP(0);
     __shared__ uint32_t h_key[CH_SLOTS];
     __shared__ uint16_t h_val[CH_SLOTS];
-    __shared__ uint32_t c_end[MAXCAND], c_nout[MAXCAND], c_info[MAXCAND];
-    __shared__ uint32_t b_off[MAXCAND], b_src[MAXCAND], b_nout[MAXCAND]; /* accepted blocks, in stream order */
-    __shared__ uint16_t b_idx[MAXCAND];
-    __shared__ uint8_t b_last[MAXCAND];
+    __shared__ __attribute__((aligned(16))) uint4 c_rec[MAXCAND]; /* candidate: end bit, bytes, info, the candidate that starts where it ends */
+    __shared__ __attribute__((aligned(16))) uint4 b_rec[MAXCAND]; /* accepted blocks in stream order: candidate | previous byte << 16, plane offset, data byte (stored), bytes */
+    __shared__ __attribute__((aligned(16))) uint4 long_win[CH_LONG]; /* windows that span many merge tiles: segment, first tile, end tile */
+    __shared__ uint32_t nlong;
+    __shared__ uint16_t jmp[CH_LEVELS * CH_JUMP]; /* jmp[k][i]: the candidate 2^k blocks behind candidate i (streams of up to CH_JUMP candidates) */
     const uint32_t s = blockIdx.x;
     const DecStream d = ds[s];
     const int lane = lane_id();
@@ -1717,10 +1911,11 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
     if (nc > (uint32_t)MAXCAND) nc = MAXCAND;
     const Cand *cs = cands + (size_t)s * MAXCAND;
     for (uint32_t i = (uint32_t)lane; i < CH_SLOTS; i += 64u) h_key[i] = CH_EMPTY;
+    if (lane == 0) nlong = 0;
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i = (uint32_t)lane; i < nc; i += 64u) {
         const Cand c = cs[i];
-        c_end[i] = c.end; c_nout[i] = c.nout; c_info[i] = c.info;
+        c_rec[i] = make_uint4(c.end, c.nout, (c.info & ~CI_BADSPAN) | (c.end <= c.bit ? CI_BADSPAN : 0u), CH_STORED);
         if (c.info & 1u) {
             uint32_t slot = (c.bit * 2654435761u) >> 21;
             for (;;) {
@@ -1732,22 +1927,98 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
         }
     }
     __builtin_amdgcn_wave_barrier();
-    /* ---- phase 1: the walk (uniform: every lane probes the same slots) ---- */
+    /* the usable candidate that starts at payload bit `bit`, or CH_STORED */
+    auto lookup = [&](uint32_t bit) -> uint32_t {
+        uint32_t slot = (bit * 2654435761u) >> 21;
+        for (uint32_t probes = 0; probes < CH_SLOTS; probes++) {
+            const uint32_t k = h_key[slot];
+            if (k == bit) return h_val[slot];
+            if (k == CH_EMPTY) break;
+            slot = (slot + 1u) & (CH_SLOTS - 1u);
+        }
+        return CH_STORED;
+    };
+    /* every candidate's successor, all of them at once (walking the blocks one by one -- a hash probe, the slot's value and
+     * three field reads per block -- was 830 clocks a block, 75 us for the 190 blocks of a plane, on a machine that has
+     * nothing else to do at that point) */
+    for (uint32_t i = (uint32_t)lane; i < nc; i += 64u) {
+        const uint4 r = c_rec[i];
+        if (r.z & 1u) c_rec[i].w = lookup(r.x);
+    }
+    __builtin_amdgcn_wave_barrier();
+    CSTAMP(1);
+    /* ---- phase 1: the walk (uniform: every lane follows the same links) ---- */
     uint32_t pos = 0, off = 0, last = 0, nblk = 0;
+    uint32_t found = lookup(0u);
+    bool have_jmp = false;
     while (!fail && off < d.n) {
         if (nblk >= (uint32_t)MAXCAND) { fail = true; break; }
-        uint32_t found = CH_STORED;
-        {
-            uint32_t slot = (pos * 2654435761u) >> 21;
-            for (uint32_t probes = 0; probes < CH_SLOTS; probes++) {
-                const uint32_t k = h_key[slot];
-                if (k == pos) { found = h_val[slot]; break; }
-                if (k == CH_EMPTY) break;
-                slot = (slot + 1u) & (CH_SLOTS - 1u);
+        if (found != CH_STORED && nc <= CH_JUMP) {
+            /* A run of dynamic blocks (normally: the whole plane), without walking it: jmp[k][i] by doubling, the length L of
+             * the list that starts at `found` by descending over k, then lane p jumps to the p-th block by the bits of p.
+             * Plane offsets are a prefix sum, the previous block's last byte a look-back over a ballot.  Whatever the
+             * step-by-step walk below rejects is rejected here too (a failed stream goes to the sequential decoder). */
+            if (!have_jmp) {
+                for (uint32_t i = (uint32_t)lane; i < nc; i += 64u) {
+                    const uint4 r = c_rec[i];
+                    jmp[i] = (uint16_t)(((r.z & 1u) && !(r.z & CI_BADSPAN)) ? r.w : CH_STORED); /* spans go forward: no cycles */
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t k = 1; k < CH_LEVELS; k++) {
+                    for (uint32_t i = (uint32_t)lane; i < nc; i += 64u) {
+                        const uint32_t j = jmp[(k - 1u) * CH_JUMP + i];
+                        jmp[k * CH_JUMP + i] = (uint16_t)(j == CH_STORED ? CH_STORED : jmp[(k - 1u) * CH_JUMP + j]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                have_jmp = true;
             }
+            uint32_t L = 1;
+            {
+                uint32_t cur = found;
+                for (int k = (int)CH_LEVELS - 1; k >= 0; k--) {
+                    const uint32_t j = jmp[(uint32_t)k * CH_JUMP + cur];
+                    if (j != CH_STORED) { cur = j; L += 1u << k; }
+                }
+            }
+            if (L > CH_JUMP) L = CH_JUMP; /* (cannot happen: the list has at most nc nodes) */
+            bool done = false;
+            for (uint32_t p0 = 0; p0 < L && !fail && !done; p0 += 64u) {
+                const uint32_t p = p0 + (uint32_t)lane;
+                const bool live = p < L;
+                uint32_t node = found;
+                for (uint32_t k = 0; k < CH_LEVELS; k++)
+                    if (live && ((p >> k) & 1u)) node = jmp[k * CH_JUMP + node];
+                uint4 r = make_uint4(0, 0, 0, 0);
+                if (live) r = c_rec[node];
+                uint32_t tot;
+                const uint32_t myoff = off + wave_excl_sum(live ? r.y : 0u, &tot);
+                /* the walk ends with the block that completes the plane; a block that overshoots it, a span that does not go
+                 * forward, or a final block in front of the end fail the stream */
+                const unsigned long long over = __ballot(live && (myoff + r.y > d.n || (r.z & CI_BADSPAN) || ((r.z & 4u) && myoff + r.y < d.n)));
+                const unsigned long long full = __ballot(live && myoff + r.y >= d.n);
+                uint32_t take = L - p0 < 64u ? L - p0 : 64u; /* blocks of this round that are accepted */
+                if (full) { take = (uint32_t)__ffsll((long long)full); done = true; }
+                if (over & (take >= 64u ? ~0ull : ((1ull << take) - 1ull))) { fail = true; break; }
+                if (nblk + take > (uint32_t)MAXCAND) { fail = true; break; }
+                const bool mine = (uint32_t)lane < take;
+                const unsigned long long lits = __ballot(mine && (r.z >> 8) != 0u);
+                const unsigned long long below = lits & ((1ull << lane) - 1ull);
+                const uint32_t lb = (r.z >> 8) & 0xffu;
+                const uint32_t prevlit = __shfl(lb, below ? 63 - __clzll((long long)below) : 0);
+                if (mine) b_rec[nblk + (uint32_t)lane] = make_uint4(node | ((below ? prevlit : last) << 16), myoff, 0u, r.y);
+                if (lits) last = __shfl(lb, 63 - __clzll((long long)lits));
+                const uint32_t lastlane = take - 1u;
+                off = __shfl(myoff + r.y, (int)lastlane);
+                pos = __shfl(r.x, (int)lastlane);
+                nblk += take;
+            }
+            found = CH_STORED; /* what follows the run, if anything, is a stored block */
+            continue;
         }
-        uint32_t cend, cnout, cinfo, stored_src = 0;
-        if (found == CH_STORED) {
+        uint32_t cend, cnout, cinfo, stored_src = 0, next = CH_STORED;
+        const bool stored_blk = found == CH_STORED;
+        if (stored_blk) {
             /* no dynamic-header candidate here: zlib stores incompressible blocks (typically the first and
              * the last block of a near-random plane); a stored block is sized from its LEN field directly */
             const uint64_t g0 = d.payoff * 8ull + pos;
@@ -1760,17 +2031,48 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
             stored_src = (db >> 3) + 4u; /* payload byte where the block's data starts */
             cinfo = 3u | (l ? ((0x100u | (uint32_t)rec[d.payoff + stored_src + l - 1u]) << 8) : 0u);
             if (l == 0u && off < d.n && cend >= d.paylen * 8u) { fail = true; break; } /* only the sync marker is left */
-        } else { cend = c_end[found]; cnout = c_nout[found]; cinfo = c_info[found]; }
+        } else { const uint4 r = c_rec[found]; cend = r.x; cnout = r.y; cinfo = r.z; next = r.w; }
         if (off + cnout > d.n || cend <= pos) { fail = true; break; }
-        if (lane == 0) { b_idx[nblk] = (uint16_t)found; b_off[nblk] = off; b_src[nblk] = stored_src; b_nout[nblk] = cnout; b_last[nblk] = (uint8_t)last; }
+        if (lane == 0) b_rec[nblk] = make_uint4(found | (last << 16), off, stored_src, cnout);
         nblk++;
         off += cnout;
         if (cinfo >> 8) last = (cinfo >> 8) & 0xffu;
         pos = cend;
         if ((cinfo & 4u) && off < d.n) { fail = true; break; } /* a final block before the plane is complete */
+        if (stored_blk && cnout != 0u && off < d.n) {
+            /* A near-random plane that zlib did deflate is a couple of hundred stored blocks of one length, back to back and
+             * byte aligned, and sizing them one after the other is a chain of dependent memory round trips.  Lane k looks at
+             * where block k + 1 of such a run would begin -- same LEN, its complement, no dynamic-header candidate at that
+             * bit -- and the run is accepted as far as every lane before agrees; the walk goes on behind it. */
+            const uint32_t l = cnout;
+            const uint32_t hb = (pos >> 3) + (uint32_t)lane * (l + 5u); /* payload byte of the block's header bits */
+            bool okk = (uint64_t)hb + 5u + l <= (uint64_t)d.paylen && d.payoff + hb + 5u + l <= reclen;
+            uint32_t lastb = 0;
+            if (okk) {
+                const uint8_t *hp = rec + d.payoff + hb;
+                const uint32_t h0 = hp[0], ln = (uint32_t)hp[1] | ((uint32_t)hp[2] << 8), nl = (uint32_t)hp[3] | ((uint32_t)hp[4] << 8);
+                okk = (h0 & 7u) == 0u && ln == l && (ln ^ 0xffffu) == nl;
+                lastb = hp[4u + l];
+            }
+            if (okk) okk = lookup(hb * 8u) == CH_STORED;
+            const unsigned long long agree = __ballot(okk);
+            uint32_t m = agree == ~0ull ? 64u : (uint32_t)__ffsll((long long)~agree) - 1u;
+            if (m > (d.n - off) / l) m = (d.n - off) / l;
+            if (m > (uint32_t)MAXCAND - nblk) m = (uint32_t)MAXCAND - nblk;
+            const uint32_t prevb = __shfl_up(lastb, 1);
+            if ((uint32_t)lane < m)
+                b_rec[nblk + (uint32_t)lane] = make_uint4(CH_STORED | ((lane == 0 ? last : prevb) << 16), off + (uint32_t)lane * l, hb + 5u, l);
+            if (m) {
+                last = (uint32_t)__shfl(lastb, (int)m - 1);
+                off += m * l; nblk += m; pos += m * (l + 5u) * 8u;
+            }
+        }
+        found = stored_blk ? lookup(pos) : next;
     }
     if (!fail && off != d.n) fail = true;
     __builtin_amdgcn_wave_barrier();
+    CSTAMP(2);
+    if (dbg && threadIdx.x == 0) { dbg[blockIdx.x * 8u + 5] = nblk; dbg[blockIdx.x * 8u + 6] = nc; }
     /* ---- phase 2: one block per lane -> its segments ---- */
     uint32_t nsg = 0;
     for (uint32_t j0 = 0; !fail && j0 < nblk; j0 += 64u) {
@@ -1780,10 +2082,11 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
 #pragma unroll
         for (int w = 0; w < CAND_WINDOWS; w++) { wl[w] = 0; wb[w] = 0; }
         if (j < nblk) {
-            boff = b_off[j]; nout = b_nout[j]; bl = b_last[j];
-            if (b_idx[j] == CH_STORED) { stored = true; wl[0] = nout; wb[0] = b_src[j]; nlive = nout ? 1u : 0u; }
+            const uint4 br = b_rec[j];
+            boff = br.y; nout = br.w; bl = br.x >> 16;
+            if ((br.x & 0xffffu) == CH_STORED) { stored = true; wl[0] = nout; wb[0] = br.z; nlive = nout ? 1u : 0u; }
             else {
-                const Cand &c = cs[b_idx[j]];
+                const Cand &c = cs[br.x & 0xffffu];
                 const uint32_t nw = c.nwin;
                 lead = c.lead < nout ? c.lead : nout;
                 uint32_t sum = 0;
@@ -1813,16 +2116,30 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
                 else if (g.fill_until < p + l) g.fill_until = p + l; /* (such a window lies in front of the block's first literal: it is inside the lead anyway) */
             }
             sg[k] = g;
-            /* tiles whose first position lies in this segment (a window holds a few; the megabyte-long windows of an
-             * all-zero plane are one or two per stream) */
-            for (uint32_t t = (p + MTILE - 1u) / MTILE; t * MTILE < p + l; t++) ix[t] = (uint16_t)k;
+            /* tiles whose first position lies in this segment: a window holds a few; the megabyte-long windows of an
+             * all-zero plane (one or two per stream, 1536 tiles) are left to the whole wave below */
+            const uint32_t t0 = (p + MTILE - 1u) / MTILE, t1 = (p + l + MTILE - 1u) / MTILE;
+            uint32_t slot = CH_LONG;
+            if (t1 - t0 > 16u) slot = atomicAdd(&nlong, 1u);
+            if (slot < CH_LONG) long_win[slot] = make_uint4(k, t0, t1, 0u);
+            else for (uint32_t t = t0; t < t1; t++) ix[t] = (uint16_t)k;
             k++;
             p += l;
         }
         nsg += tot;
     }
+    __builtin_amdgcn_wave_barrier();
+    if (!fail) {
+        const uint32_t nl = nlong < CH_LONG ? nlong : CH_LONG;
+        for (uint32_t e = 0; e < nl; e++) {
+            const uint4 lw = long_win[e];
+            for (uint32_t t = lw.y + (uint32_t)lane; t < lw.z; t += 64u) ix[t] = (uint16_t)lw.x;
+        }
+    }
     if (fail) { single(SEG_PLANES | ((uint64_t)s * CHK)); if (lane == 0) fallback[s] = 1u; return; } /* k_inflate_par decodes it into the plane buffer */
     if (lane == 0) { nseg[s] = nsg; fallback[s] = 0u; }
+    CSTAMP(3);
+#undef CSTAMP
 }
 
 __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ rec, uint64_t reclen,
