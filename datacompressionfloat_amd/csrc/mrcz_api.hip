@@ -168,7 +168,7 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->use_hint = 1;
     ctx->huff_split = 1;
     ctx->validate_wave = 1;
-    ctx->validate_grid = 4096;
+    ctx->validate_grid = 0; /* 0 = by the batch's stream count */
     if (const char *ev = getenv("MRCZ_VALIDATE_WAVE")) ctx->validate_wave = atoi(ev) ? 1u : 0u;
     if (const char *ev = getenv("MRCZ_VALIDATE_GRID")) { const int v = atoi(ev); if (v >= 1 && v <= 65535) ctx->validate_grid = (uint32_t)v; }
     if (const char *ev = getenv("MRCZ_HUFF_SPLIT")) ctx->huff_split = atoi(ev) ? 1u : 0u;
@@ -562,8 +562,8 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
             ctx->calltag = ctx->calltag * 0x01000193u + 0x9e3779b9u;
             LAUNCH("k_scan_candidates", k_scan_candidates, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(64), rec, len,
                    ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 4, ctx->rawcap);
-            if (ctx->validate_wave)
-                LAUNCH("k_validate_candidates", k_validate_wave, dim3(ctx->validate_grid), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 4,
+            if (ctx->validate_wave) /* ~280 signature survivors per stream; the more waves in flight, the better their memory round trips overlap (1 GiB: 2048 waves 279 us, 8192 159, 32768 128) */
+                LAUNCH("k_validate_candidates", k_validate_wave, dim3(ctx->validate_grid ? ctx->validate_grid : (ns * 192u < 4096u ? 4096u : ns * 192u > 32768u ? 32768u : ns * 192u)), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 4,
                        ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag);
             else
                 LAUNCH("k_validate_candidates", k_validate_candidates, dim3(2048), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 4,

@@ -1589,13 +1589,14 @@ __global__ __launch_bounds__(64) void k_validate_wave(const uint8_t *__restrict_
     const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
     const uint64_t nrec32 = reclen >> 2;
     const uint32_t segcap = rawcap / RAW_SEGS;
-    if (lane == 0) {
-        uint32_t acc = 0;
-        for (uint32_t g = 0; g < RAW_SEGS; g++) { segbase[g] = acc; const uint32_t c = nraw[g]; acc += c < segcap ? c : segcap; }
-        segbase[RAW_SEGS] = acc;
+    static_assert(RAW_SEGS == 64, "one raw-list segment per lane");
+    uint32_t total;
+    {
+        const uint32_t c = nraw[lane];
+        segbase[lane] = wave_excl_sum(c < segcap ? c : segcap, &total);
+        if (lane == 0) segbase[RAW_SEGS] = total;
     }
     __syncthreads();
-    const uint32_t total = segbase[RAW_SEGS];
     /* hw[0 .. VH_WORDS + 1] = the record words from word `wb` on */
     auto stage = [&](uint64_t wb) {
         for (uint32_t w = (uint32_t)lane; w < (uint32_t)VH_WORDS + 2u; w += 64u) {

@@ -167,6 +167,21 @@ def test_huffman_header_paths_agree(monkeypatch):
     mono.close(); split.close()
 
 
+def test_header_validators_agree(monkeypatch, oracle):
+    # candidate headers are parsed one wave each by default, one lane each with MRCZ_VALIDATE_WAVE=0: both must hand every
+    # block of every stream to the parallel decoder (no fallbacks) and decode the same bytes
+    from datacompressionfloat_amd import MrcZipCodec
+    monkeypatch.setenv("MRCZ_VALIDATE_WAVE", "0")
+    lanes = MrcZipCodec(0, max_batch_chunks=4)
+    monkeypatch.setenv("MRCZ_VALIDATE_WAVE", "1")
+    waves = MrcZipCodec(0, max_batch_chunks=4)
+    for w, bits in ((util.gauss_words(2_000_000, seed=3), 8), (util.poisson_words(1_500_000, seed=4), 0),
+                    (util.runs_words(1_000_000, [1, 2, 3, 300, 5000], 3, seed=8), 0), (util.kat_words(700_000), 12)):
+        for c in (lanes, waves):
+            _roundtrip(c, oracle, w, bits)
+    lanes.close(); waves.close()
+
+
 def test_planes_that_begin_with_stored_blocks(codec, oracle):
     # noise, then constants: the stream of every plane starts with STORED blocks and goes on with coded ones (see tests/test_sim.py)
     rng = np.random.default_rng(11)
