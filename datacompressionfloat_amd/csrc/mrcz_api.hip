@@ -45,6 +45,7 @@ struct mrcz_ctx {
     uint32_t lanes;                /* lanes per compress batch: 2 measured best (1: 292, 2: 306, 3: 307, 4: 229 GB/s -- with four
                                     * Huffman kernels resident their 72 KB workgroups starve the streaming kernels of LDS);
                                     * MRCZ_LANES overrides it for experiments */
+    int trace;                     /* MRCZ_TRACE: the synchronous calls print how long their enqueue and the wait for the device took */
     char err[256];
     /* workspace (sized for max_chunks chunks = 4*max_chunks streams) */
     TileSum *tsum;
@@ -136,6 +137,7 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     mrcz_ctx *ctx = (mrcz_ctx *)calloc(1, sizeof(mrcz_ctx));
     if (!ctx) return MRCZ_ENOMEM;
     ctx->device = device;
+    ctx->trace = trace ? 1 : 0;
     ctx->max_chunks = max_batch_chunks;
     if (hipSetDevice(device) != hipSuccess) { free(ctx); return MRCZ_EHIP; }
     t_dev = wall_now();
@@ -489,8 +491,11 @@ extern "C" int mrcz_compress_chunks(mrcz_ctx_t *ctx, const void *d_in, uint64_t 
     if (!ctx || !out_len) return MRCZ_EINVAL;
     *out_len = 0;
     if (nfloats == 0) { ctx->ntimers = 0; return (d_in && d_out) ? MRCZ_OK : MRCZ_EINVAL; }
+    const double t0 = ctx->trace ? wall_now() : 0.0;
     if (int rc = compress_enqueue(ctx, d_in, nfloats, first_chunk, bits, d_out, out_cap, ctx->h_result, 0)) return rc;
+    const double t1 = ctx->trace ? wall_now() : 0.0;
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (compress)");
+    if (ctx->trace) fprintf(stderr, "[mrcz trace] compress %llu floats: enqueue %.1f us, wait %.1f us\n", (unsigned long long)nfloats, 1e6 * (t1 - t0), 1e6 * (wall_now() - t1));
     *out_len = ctx->h_result[0];
     if (plane_bytes)
         for (int j = 0; j < 4; j++) plane_bytes[j] = ctx->h_result[1 + j];
@@ -560,8 +565,12 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
         if (ctx->phase_profile != 1) { /* (1 = profiling vehicle: every stream through the sequential-chain kernel with phase counters) */
             /* block-parallel path: find block starts, size every candidate block, close the chains, write */
             ctx->calltag = ctx->calltag * 0x01000193u + 0x9e3779b9u;
-            LAUNCH("k_scan_candidates", k_scan_candidates, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(64), rec, len,
-                   ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 4, ctx->rawcap);
+            if (ns <= 48u)
+                LAUNCH("k_scan_candidates", k_scan_candidates<SLAB_BYTES_SMALL>, dim3((CHK + (CHK >> 3) + SLAB_BYTES_SMALL - 1) / SLAB_BYTES_SMALL, ns), dim3(64), rec, len,
+                       ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 4, ctx->rawcap);
+            else
+                LAUNCH("k_scan_candidates", k_scan_candidates<SLAB_BYTES>, dim3((CHK + (CHK >> 3) + SLAB_BYTES - 1) / SLAB_BYTES, ns), dim3(64), rec, len,
+                       ctx->dstreams, ctx->cands, ctx->ncand, ctx->rawlist, ctx->njobs + 4, ctx->rawcap);
             if (ctx->validate_wave) /* ~280 signature survivors per stream; the more waves in flight, the better their memory round trips overlap (1 GiB: 2048 waves 279 us, 8192 159, 32768 128) */
                 LAUNCH("k_validate_candidates", k_validate_wave, dim3(ctx->validate_grid ? ctx->validate_grid : (ns * 192u < 4096u ? 4096u : ns * 192u > 32768u ? 32768u : ns * 192u)), dim3(64), rec, len, ctx->dstreams, ctx->rawlist, ctx->njobs + 4,
                        ctx->rawcap, ctx->cands, ctx->ncand, ctx->hdrs, ctx->calltag);
@@ -594,8 +603,11 @@ extern "C" int mrcz_uncompress_chunks(mrcz_ctx_t *ctx, const void *d_records, ui
     if (!ctx || !d_out) return MRCZ_EINVAL;
     if (consumed) *consumed = 0;
     if (nfloats == 0) { ctx->ntimers = 0; return MRCZ_OK; }
+    const double t0 = ctx->trace ? wall_now() : 0.0;
     if (int rc = uncompress_enqueue(ctx, d_records, len, nfloats, chk, d_out, ctx->h_result, 0, 0)) return rc;
+    const double t1 = ctx->trace ? wall_now() : 0.0;
     HIPCHK(hipStreamSynchronize(ctx->stream), "stream sync (uncompress)");
+    if (ctx->trace) fprintf(stderr, "[mrcz trace] uncompress %llu floats: enqueue %.1f us, wait %.1f us\n", (unsigned long long)nfloats, 1e6 * (t1 - t0), 1e6 * (wall_now() - t1));
     if (consumed) *consumed = ctx->h_result[0];
     ctx->last_fallbacks = ctx->h_result[2];
     if (ctx->h_result[1]) return fail(ctx, MRCZ_EFORMAT, "malformed chunk records or deflate stream", hipSuccess);

@@ -1216,17 +1216,19 @@ struct Cand {
  * code-length code (Kraft sum exactly 1).  Survivors are block-start CANDIDATES; correctness never
  * depends on them (k_chain only accepts a candidate that the previous block's END_BLOCK lands on, and
  * any stream whose chain cannot be closed is decoded sequentially instead). */
-constexpr int SLAB_BYTES = 32768;
+constexpr int SLAB_BYTES = 32768;      /* payload bytes one scanning wave covers in large batches ... */
+constexpr int SLAB_BYTES_SMALL = 8192;  /* ... and in small ones, where the kernel lasts as long as one wave (64 MiB: 79 -> 25 us) */
+template <int SLAB>
 __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                         const DecStream *__restrict__ ds, Cand *__restrict__ cands,
                                                         uint32_t *__restrict__ ncand, uint2 *__restrict__ rawlist,
                                                         uint32_t *__restrict__ nraw, uint32_t rawcap)
 {
-    /* one wave per 32 KiB slab of one stream's payload; no workgroup barriers anywhere */
+    /* one wave per SLAB bytes of one stream's payload; no workgroup barriers anywhere */
     const uint32_t s = blockIdx.y;
     const DecStream d = ds[s];
     if (d.raw) return;
-    const uint32_t slab0 = blockIdx.x * SLAB_BYTES;
+    const uint32_t slab0 = blockIdx.x * SLAB;
     if (slab0 >= d.paylen) return;
     const uint32_t paybits = d.paylen * 8u;
     const uint32_t lane = threadIdx.x;
@@ -1265,8 +1267,8 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
         __builtin_amdgcn_wave_barrier();
     };
     const uint64_t w_first = (gbit0 >> 5) & ~3ull; /* 16-byte aligned dword index at or before the slab (positions are global bits) */
-    const uint64_t bit_lo = gbit0, bit_hi = gbit0 + 8ull * SLAB_BYTES;
-    constexpr int NSTEP = SLAB_BYTES / 16 / 64 + 1;
+    const uint64_t bit_lo = gbit0, bit_hi = gbit0 + 8ull * SLAB;
+    constexpr int NSTEP = SLAB / 16 / 64 + 1;
     auto load4 = [&](uint64_t wi, uint32_t w[4]) {
         if (wi + 4 <= nrec32) {
             const uint4 v = *reinterpret_cast<const uint4 *>(rec32 + wi);
