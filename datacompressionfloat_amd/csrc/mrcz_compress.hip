@@ -318,31 +318,36 @@ __device__ __forceinline__ void load_plane_row(const uint8_t *__restrict__ pl, u
  * mostly verbatim or masked to zero) so that the tail of a (segment, chunk, plane) grid is made of short waves */
 __device__ __forceinline__ int plane_of_slot(uint32_t z) { return (int)((0x0132u >> (4u * z)) & 3u); }
 
-__global__ __launch_bounds__(64) void k_histogram(const uint8_t *__restrict__ planes, uint64_t nfloats,
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_histogram(const uint8_t *__restrict__ planes, uint64_t nfloats,
                                                   const TileInfo *__restrict__ tinfo, uint16_t *__restrict__ pairhist,
                                                   uint32_t *__restrict__ blkstart, uint32_t *__restrict__ slideq)
 {
-    /* one wave = one (segment, plane) */
-    __shared__ uint32_t rows[2][HROW];
+    /* one workgroup = one (segment, plane), its W waves take the segment's tiles in turn.  A tile knows its block from its
+     * symbol prefix (TileInfo::P), and a segment's 32768 positions touch at most three blocks: one LDS row per block, all
+     * waves add into them, and the rows go out together at the end.  (One wave per segment walking its eight tiles was as
+     * long as that walk, 0.2 ms, however small the batch.) */
+    __shared__ uint32_t rows[4 * HROW]; /* row r at rows + r * HROW */
+    __shared__ uint32_t endsym; /* symbols in front of the segment's end */
     const uint32_t g = blockIdx.x, c = blockIdx.y;
     const uint64_t cbase = (uint64_t)c * CHK;
     const uint32_t n = (uint32_t)((nfloats - cbase) < CHK ? (nfloats - cbase) : CHK);
     if ((uint64_t)g * SEG >= n) return;
-    const int lane = lane_id(), w = plane_of_slot(blockIdx.z);
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6), w = plane_of_slot(blockIdx.z);
     const uint32_t s = 4u * c + (uint32_t)w;
     const uint8_t *pl = planes + (size_t)s * CHK;
-    uint32_t *rowA = rows[0], *rowB = rows[1];
-    for (int i = lane; i < HROW; i += 64) { rowA[i] = 0; rowB[i] = 0; }
-    __builtin_amdgcn_wave_barrier();
+    for (int i = (int)threadIdx.x; i < 4 * HROW; i += 64 * W) rows[i] = 0;
+    const uint32_t blk0 = tinfo[(size_t)s * TPS + (g * SEG) / TILE].P / BLK_SYMS;
+    if (W > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     const uint32_t nslide = slide_count(n);
-    uint32_t curBlk = 0xffffffffu;
 
-    for (int ti = 0; ti < TILES_PER_SEG; ti++) {
+    for (int ti = wv; ti < TILES_PER_SEG; ti += W) {
         const uint32_t t0 = g * SEG + ti * TILE;
         if (t0 >= n) break;
         const int len = (int)((n - t0) < (uint32_t)TILE ? (n - t0) : (uint32_t)TILE);
         const TileInfo tinf = tinfo[(size_t)s * TPS + (t0 / TILE)];
-        if (curBlk == 0xffffffffu) curBlk = tinf.P / BLK_SYMS;
+        const uint32_t curBlk = tinf.P / BLK_SYMS;
+        uint32_t *rowA = rows + (curBlk - blk0) * HROW, *rowB = rowA + HROW;
         uint32_t x[16];
         load_plane_row(pl, t0, len, lane, x);
         const LaneTile lt = analyse_lane(x, lane, len, tinf.B, tinf.F);
@@ -442,25 +447,15 @@ __global__ __launch_bounds__(64) void k_histogram(const uint8_t *__restrict__ pl
                 atomicAdd(&r[286], 1u);
             }
         }
-        __builtin_amdgcn_wave_barrier(); /* this wave's row updates are complete */
-        /* crossed (or exactly reached) the block boundary: retire row A */
-        if (tinf.P + tot >= nextBnd) {
-            uint16_t *dst = pairhist + ((size_t)s * MAXPAIR + (g + curBlk)) * HROW;
-            for (int i = lane; i < HROW; i += 64) {
-                dst[i] = (uint16_t)rowA[i];
-                rowA[i] = rowB[i];
-                rowB[i] = 0;
-            }
-            curBlk++;
-            __builtin_amdgcn_wave_barrier();
-        }
+        if ((ti == TILES_PER_SEG - 1 || t0 + (uint32_t)TILE >= n) && lane == 0) endsym = tinf.P + tot;
     }
-    /* segment end: always retire the open row (possibly empty) so every pair (g, b) with
-     * b in [blk(P_g), blk(P_{g+1})] exists */
-    {
-        __builtin_amdgcn_wave_barrier();
-        uint16_t *dst = pairhist + ((size_t)s * MAXPAIR + (g + curBlk)) * HROW;
-        for (int i = lane; i < HROW; i += 64) dst[i] = (uint16_t)rowA[i];
+    /* segment end: the rows of every block the segment reaches -- a block whose boundary it reaches exactly included, as
+     * an empty row -- so that every pair (g, b) with b in [blk(P_g), blk(P_{g+1})] exists */
+    if (W > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    const uint32_t nrows = endsym / BLK_SYMS - blk0 + 1u;
+    for (uint32_t r = 0; r < nrows && r < 4u; r++) {
+        uint16_t *dst = pairhist + ((size_t)s * MAXPAIR + (g + blk0 + r)) * HROW;
+        for (int i = (int)threadIdx.x; i < HROW; i += 64 * W) dst[i] = (uint16_t)rows[r * HROW + i];
     }
 }
 
