@@ -1574,13 +1574,16 @@ __global__ __launch_bounds__(64) void k_validate_candidates(const uint8_t *__res
  *     the Kraft sum, the stores -- is done by the marked lanes together;
  *   - false candidates decode noise, whose zero runs reach HLIT + HDIST lengths within two or three rounds.
  * The accepted candidates and their HdrCache rows are the same as the per-lane kernel's (same tests), in another order. */
+/* record words one wave stages at a time: 128 bytes.  Headers of this codec are 100-160 bytes, so the window is moved up once
+ * for about every other candidate -- that path is part of every test run, not a corner case. */
+constexpr int VW_WORDS = 32;
 __global__ __launch_bounds__(64) void k_validate_wave(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                       const DecStream *__restrict__ ds, const uint2 *__restrict__ rawlist,
                                                       const uint32_t *__restrict__ nraw, uint32_t rawcap,
                                                       Cand *__restrict__ cands, uint32_t *__restrict__ ncand,
                                                       HdrCache *__restrict__ hdrs, uint32_t calltag)
 {
-    __shared__ uint32_t hw[VH_WORDS + 2];
+    __shared__ uint32_t hw[VW_WORDS + 2];
     __shared__ uint8_t tab[128];
     __shared__ uint32_t lens32[84];
     __shared__ uint8_t cl[32];
@@ -1599,9 +1602,9 @@ __global__ __launch_bounds__(64) void k_validate_wave(const uint8_t *__restrict_
         if (lane == 0) segbase[RAW_SEGS] = total;
     }
     __syncthreads();
-    /* hw[0 .. VH_WORDS + 1] = the record words from word `wb` on */
+    /* hw[0 .. VW_WORDS + 1] = the record words from word `wb` on */
     auto stage = [&](uint64_t wb) {
-        for (uint32_t w = (uint32_t)lane; w < (uint32_t)VH_WORDS + 2u; w += 64u) {
+        for (uint32_t w = (uint32_t)lane; w < (uint32_t)VW_WORDS + 2u; w += 64u) {
             const uint64_t wi = wb + w;
             uint32_t v = 0;
             if (wi < nrec32) v = rec32[wi];
@@ -1610,7 +1613,7 @@ __global__ __launch_bounds__(64) void k_validate_wave(const uint8_t *__restrict_
         }
         __builtin_amdgcn_wave_barrier();
     };
-    /* >= 32 bits from bit `bp` of the staged words (bp < 32 * VH_WORDS) */
+    /* >= 32 bits from bit `bp` of the staged words (bp < 32 * VW_WORDS) */
     auto peek = [&](uint32_t bp) -> uint32_t {
         const uint32_t i = bp >> 5;
         const unsigned long long v = (unsigned long long)hw[i] | ((unsigned long long)hw[i + 1u] << 32);
@@ -1661,7 +1664,7 @@ __global__ __launch_bounds__(64) void k_validate_wave(const uint8_t *__restrict_
         uint32_t idx = 0, prevlen = 0;            /* lengths decoded so far, the last one (uniform) */
         uint32_t kr = 0;                           /* this lane's share of the literal/length code's Kraft sum */
         while (ok && idx < total_l) {
-            if (cur + 64u + 14u + 32u > 32u * (uint32_t)VH_WORDS) { /* a long header: move the staged window up */
+            if (cur + 64u + 14u + 32u > 32u * (uint32_t)VW_WORDS) { /* a long header: move the staged window up */
                 wb += cur >> 5;
                 cur &= 31u;
                 __builtin_amdgcn_wave_barrier();

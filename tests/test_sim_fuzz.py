@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))
 import util
 lib = ctypes.CDLL(os.environ["SIM_ASAN"])
 sim = util.SimCodec(lib)
-rng = np.random.default_rng(11)
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "11")))
 words = util.gauss_words(36000, seed=3)
 good = sim.compress_records(words, 8)
 assert np.array_equal(sim.uncompress_records(good, len(words)), util.erase_expected(words, 8))
