@@ -102,8 +102,8 @@ def cpu_baseline(sample_words, bits, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bits", type=int, default=8)
     ap.add_argument("--gib-per-gpu", type=float, default=1.0)
     ap.add_argument("--stream", action="store_true", help="streaming mode (device-generated App. D volume, batches of 128 chunks); implied above 4 GiB")

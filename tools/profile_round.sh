@@ -9,8 +9,8 @@ TAG=${1:-r01}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 5 --warmup 2 > $O/${TAG}_bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/stats.err
+python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/stats.err
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $O/fetch.err
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $O/write.err
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats_bench_1GiB_b8.csv
