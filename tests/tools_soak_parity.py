@@ -6,7 +6,8 @@ Every case builds a volume out of random segments (noise, byte runs of critical 
 of a few distributions, constant stretches that span block and chunk borders), picks a mask level, and checks
   - the container bytes against oracle.compress (byte identity),
   - the round trip against the erased input,
-  - that no stream fell back to the sequential decoder.
+  - that no stream fell back to the sequential decoder;
+one case in ten runs in "-s int" mode (container against oracle.compress_int, round trip against the quantised input).
 Prints one line per failure (with the case's seed, so it can be rebuilt) and a summary; exit code 1 on any failure.
 Lives under tests/ because it uses the oracle (test infrastructure); the product never does.
 """
@@ -82,23 +83,30 @@ def main():
         w = volume(rng)
         bits = int(rng.choice([0, 0, 0, 1, 4, 7, 8, 9, 12, 15, 16, 17, 20, 23, 24, 25, 28, 31, 32]))
         data = w.tobytes()
+        int_mode = len(w) > 256 and rng.random() < 0.1  # "-s int": the quantiser instead of the mask (workers.c:125-175)
         try:
-            z = codec.zip_bytes(data, bits)
-            ref = oracle.compress(data, bits)
             what = None
-            if z != ref:
-                what = "container differs (%d vs %d bytes)" % (len(z), len(ref))
+            if int_mode:
+                z = codec.zip_bytes(data, 0, mode="int")
+                ref = oracle.compress_int(data)
+                if z != ref:
+                    what = "int-mode container differs (%d vs %d bytes)" % (len(z), len(ref))
+                elif codec.unzip_bytes(z, mode="int") != util.int_mode_expected(w).tobytes():
+                    what = "int-mode round trip differs"
             else:
-                back = codec.unzip_bytes(z)
-                if back != util.erase_expected(w, bits).tobytes():
+                z = codec.zip_bytes(data, bits)
+                ref = oracle.compress(data, bits)
+                if z != ref:
+                    what = "container differs (%d vs %d bytes)" % (len(z), len(ref))
+                elif codec.unzip_bytes(z) != util.erase_expected(w, bits).tobytes():
                     what = "round trip differs"
-                elif codec.last_fallbacks() != 0:
-                    what = "%d streams fell back to the sequential decoder" % codec.last_fallbacks()
+            if what is None and codec.last_fallbacks() != 0:
+                what = "%d streams fell back to the sequential decoder" % codec.last_fallbacks()
         except Exception as e:  # noqa: BLE001
             what = "exception %r" % (e,)
         if what:
             fails += 1
-            print("FAIL case seed=%d n=%d bits=%d: %s" % (seed, len(w), bits, what), flush=True)
+            print("FAIL case seed=%d n=%d bits=%d int=%d: %s" % (seed, len(w), bits, int(int_mode), what), flush=True)
         cases += 1
         nbytes += len(data)
         if cases % 50 == 0:
