@@ -1644,7 +1644,7 @@ __global__ __launch_bounds__(64) void k_validate_wave(const uint8_t *__restrict_
         if ((uint32_t)lane < ncode) cl[k_bl_order(lane)] = (uint8_t)(peek(cur0 + 17u + 3u * (uint32_t)lane) & 7u);
         __builtin_amdgcn_wave_barrier();
         const uint32_t mylen = lane < 19 ? (uint32_t)cl[lane] : 0u;
-        uint32_t code = 0, next = 0, blkraft = 0, mycode = 0;
+        uint32_t next = 0, blkraft = 0, mycode = 0;
 #pragma unroll
         for (uint32_t l = 1; l <= 7u; l++) {
             const unsigned long long same = __ballot(mylen == l);
@@ -1653,7 +1653,6 @@ __global__ __launch_bounds__(64) void k_validate_wave(const uint8_t *__restrict_
             blkraft += cnt << (7u - l);
             next = (next + cnt) << 1;
         }
-        (void)code;
         ok = ok && blkraft == 128u; /* complete code: every table entry gets written */
         if (ok && mylen) {
             const uint32_t r = __brev(mycode) >> (32u - mylen);

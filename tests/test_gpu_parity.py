@@ -188,6 +188,10 @@ def test_planes_that_begin_with_stored_blocks(codec, oracle):
     w = np.concatenate([rng.integers(0, 2**32, 300000, dtype=np.uint64).astype(np.uint32), np.full(400000, 0x41200000, np.uint32)])
     _roundtrip(codec, oracle, w, 0)
     assert codec.last_fallbacks() == 0
+    # coded blocks, a run of stored ones, coded blocks again (see tests/test_sim.py)
+    low = lambda n: rng.integers(0, 7, n, dtype=np.uint64).astype(np.uint32) * np.uint32(0x01010101)
+    w = np.concatenate([low(800000), rng.integers(0, 2**32, 500000, dtype=np.uint64).astype(np.uint32), low(900000)])
+    _roundtrip(codec, oracle, w, 0)
 
 
 def test_chunk_boundaries(codec, oracle):

@@ -60,6 +60,11 @@ def test_planes_that_begin_with_stored_blocks(simlib, oracle):
     for nn, nz in ((34000, 40000), (70000, 70000)):
         w = np.concatenate([rng.integers(0, 2**32, nn, dtype=np.uint64).astype(np.uint32), np.full(nz, 0x41200000, np.uint32)])
         _check(simlib, oracle, w, 0)
+    # coded blocks, a run of stored ones, coded blocks again: k_chain ranks the first run of dynamic blocks, walks the stored
+    # ones (speculating on their common length) and ranks the second run from where they end
+    low = lambda n: rng.integers(0, 7, n, dtype=np.uint64).astype(np.uint32) * np.uint32(0x01010101)
+    w = np.concatenate([low(80000), rng.integers(0, 2**32, 100000, dtype=np.uint64).astype(np.uint32), low(90000)])
+    _check(simlib, oracle, w, 0)
 
 
 def test_tile_of_long_codes_exceeds_the_emit_staging_buffer(simlib, oracle):
