@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64 * W) void k_histogram(const uint8_t *__restrict_
              * first bytes) count per value in the wave first: the lanes that hold the first active lane's value are
              * found with a ballot and that lane adds their number. */
             const uint32_t b0 = x[0] & 0xffu;
-            const bool fewvalues = popc64(__ballot(b0 == (uint32_t)__shfl((int)b0, 0))) >= 16;
+            const bool fewvalues = popc64(__ballot(b0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)b0))) >= 16;
             if (fewvalues) {
 #pragma unroll
                 for (int i = 0; i < 64; i++) {
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64 * W) void k_histogram(const uint8_t *__restrict_
                     unsigned long long act = __ballot(lit);
                     while (act) {
                         const int leader = ctz64(act);
-                        const uint32_t kl = (uint32_t)__shfl((int)key, leader);
+                        const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
                         const unsigned long long same = __ballot(lit && key == kl);
                         if (lane == leader) atomicAdd(&rowA[kl], (uint32_t)popc64(same));
                         act &= ~same;
