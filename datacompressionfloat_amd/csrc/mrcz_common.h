@@ -88,13 +88,21 @@ __device__ __forceinline__ uint32_t wave_sum_u(uint32_t v)
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
-/* exclusive prefix sum over lanes; total returned through *total */
+/* exclusive prefix sum over lanes; total returned through *total.  All 64 lanes must be active.
+ * Six DPP adds (shifts inside the rows of 16 lanes, then lane 15 of a row to the next row, then lane 31 to the upper half)
+ * and one scalar lane read: no LDS traffic.  The shuffle version was six ds_bpermute round trips -- most of a round of
+ * k_validate_wave, whose waves are alone on their SIMDs. */
+#define MRCZ_DPP_ADD(x, ctrl, rows) ((x) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rows), 0xf, false))
 __device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t *total)
 {
-    int l = lane_id();
     uint32_t x = v;
-    for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if (l >= d) x += y; }
-    *total = __shfl(x, 63);
+    x = MRCZ_DPP_ADD(x, 0x111, 0xf); /* row_shr:1 */
+    x = MRCZ_DPP_ADD(x, 0x112, 0xf); /* row_shr:2 */
+    x = MRCZ_DPP_ADD(x, 0x114, 0xf); /* row_shr:4 */
+    x = MRCZ_DPP_ADD(x, 0x118, 0xf); /* row_shr:8 */
+    x = MRCZ_DPP_ADD(x, 0x142, 0xa); /* row_bcast:15 into rows 1 and 3 */
+    x = MRCZ_DPP_ADD(x, 0x143, 0xc); /* row_bcast:31 into rows 2 and 3 */
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
     return x - v;
 }
 /* max over lanes strictly below this lane (neutral if none) */

@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(64) void k_validate_wave(const uint8_t *__restrict_
             const uint32_t from = (uint32_t)__shfl((int)basev, below ? 63 - __clzll((long long)below) : 0);
             const uint32_t val = !is16 ? basev : (below ? from : prevlen);
             if (__ballot(on && is16 && myidx == 0u)) { ok = false; break; } /* nothing to repeat */
-            prevlen = (uint32_t)__shfl((int)val, 63 - __clzll((long long)starts));
+            prevlen = (uint32_t)__builtin_amdgcn_readlane((int)val, 63 - __clzll((long long)starts)); /* (uniform index: a scalar lane read) */
             if (on && val) {
                 const uint32_t lo = myidx < nlen ? myidx : nlen, hi = myidx + rep < nlen ? myidx + rep : nlen;
                 kr += (hi - lo) * (32768u >> val);
@@ -1713,7 +1713,7 @@ __global__ __launch_bounds__(64) void k_validate_wave(const uint8_t *__restrict_
         if (ok && idx == total_l && kraft == 32768u && eob_s != 0u && used <= pay_end) {
             uint32_t i = 0;
             if (lane == 0) i = atomicAdd(&ncand[s], 1u);
-            i = (uint32_t)__shfl((int)i, 0);
+            i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
             if (i < (uint32_t)MAXCAND) {
                 HdrCache *hc = hdrs + ((size_t)s * MAXCAND + i);
                 uint32_t *dst = reinterpret_cast<uint32_t *>(hc->lens);
@@ -2012,10 +2012,10 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
                 const uint32_t lb = (r.z >> 8) & 0xffu;
                 const uint32_t prevlit = __shfl(lb, below ? 63 - __clzll((long long)below) : 0);
                 if (mine) b_rec[nblk + (uint32_t)lane] = make_uint4(node | ((below ? prevlit : last) << 16), myoff, 0u, r.y);
-                if (lits) last = __shfl(lb, 63 - __clzll((long long)lits));
+                if (lits) last = (uint32_t)__builtin_amdgcn_readlane((int)lb, 63 - __clzll((long long)lits));
                 const uint32_t lastlane = take - 1u;
-                off = __shfl(myoff + r.y, (int)lastlane);
-                pos = __shfl(r.x, (int)lastlane);
+                off = (uint32_t)__builtin_amdgcn_readlane((int)(myoff + r.y), (int)lastlane);
+                pos = (uint32_t)__builtin_amdgcn_readlane((int)r.x, (int)lastlane);
                 nblk += take;
             }
             found = CH_STORED; /* what follows the run, if anything, is a stored block */
@@ -2068,7 +2068,7 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
             if ((uint32_t)lane < m)
                 b_rec[nblk + (uint32_t)lane] = make_uint4(CH_STORED | ((lane == 0 ? last : prevb) << 16), off + (uint32_t)lane * l, hb + 5u, l);
             if (m) {
-                last = (uint32_t)__shfl(lastb, (int)m - 1);
+                last = (uint32_t)__builtin_amdgcn_readlane((int)lastb, (int)m - 1);
                 off += m * l; nblk += m; pos += m * (l + 5u) * 8u;
             }
         }

@@ -165,4 +165,23 @@ static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return sim_exchange(v, lane & 63); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return sim_exchange(v, 0); }
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
+/* DPP move, the controls the product uses: row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143); a lane whose row is
+ * masked out or whose source does not exist keeps `old` */
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    (void)bank_mask; (void)bound_ctrl;
+    uint64_t *slots = sim_wave_slots();
+    const int L = sim_lane(), row = L >> 4, idx = L & 15;
+    slots[L] = sim_to_bits(src);
+    sim_wave_barrier();
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if (idx >= n) from = L - n; }
+    else if (ctrl == 0x142) { if (row >= 1) from = 16 * row - 1; }
+    else if (ctrl == 0x143) { if (row >= 2) from = 31; }
+    else { fprintf(stderr, "sim: DPP control 0x%x not emulated\n", ctrl); abort(); }
+    int r = old;
+    if (from >= 0 && ((row_mask >> row) & 1)) r = sim_from_bits<int>(slots[from]);
+    sim_wave_barrier();
+    return r;
+}
 static inline int __builtin_amdgcn_writelane(int v, int lane, int old) { return sim_lane() == (lane & 63) ? v : old; }
