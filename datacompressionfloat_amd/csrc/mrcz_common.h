@@ -73,21 +73,40 @@ struct BlkLay {           /* written by k_stream_layout */
 /* ---------------- wave (64 lanes) helpers ---------------- */
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-__device__ __forceinline__ int wave_min_i(int v)
+/* Wave-wide scans and reductions by DPP: shifts inside the rows of 16 lanes (row_shr / row_shl), lane 15 of a row to the next
+ * row (row_bcast:15), lane 31 to the upper half (row_bcast:31), the whole wave by one lane (wave_shr:1 / wave_shl:1), and scalar
+ * lane reads.  No LDS traffic; the shuffle versions were six or seven ds_bpermute round trips each, and analyse_lane -- every
+ * tile of the summary, histogram and emit passes -- has two of them.  All 64 lanes must be active.  A lane without a source
+ * (row edge, masked row) gets the operation's neutral value. */
+#define MRCZ_DPP(neutral, x, ctrl, rows) __builtin_amdgcn_update_dpp((int)(neutral), (int)(x), (ctrl), (rows), 0xf, false)
+constexpr int DPP_ROW_SHR = 0x110, DPP_ROW_SHL = 0x100, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138, DPP_WAVE_SHL1 = 0x130;
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+/* inclusive prefix maximum / minimum over the lanes */
+__device__ __forceinline__ int wave_incl_max(int x)
 {
-    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = o < v ? o : v; }
-    return v;
+    constexpr int N = (int)0x80000000;
+    x = imax(x, MRCZ_DPP(N, x, DPP_ROW_SHR + 1, 0xf));
+    x = imax(x, MRCZ_DPP(N, x, DPP_ROW_SHR + 2, 0xf));
+    x = imax(x, MRCZ_DPP(N, x, DPP_ROW_SHR + 4, 0xf));
+    x = imax(x, MRCZ_DPP(N, x, DPP_ROW_SHR + 8, 0xf));
+    x = imax(x, MRCZ_DPP(N, x, DPP_BCAST15, 0xa));
+    x = imax(x, MRCZ_DPP(N, x, DPP_BCAST31, 0xc));
+    return x;
 }
-__device__ __forceinline__ int wave_max_i(int v)
+__device__ __forceinline__ int wave_incl_min(int x)
 {
-    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = o > v ? o : v; }
-    return v;
+    constexpr int N = 0x7fffffff;
+    x = imin(x, MRCZ_DPP(N, x, DPP_ROW_SHR + 1, 0xf));
+    x = imin(x, MRCZ_DPP(N, x, DPP_ROW_SHR + 2, 0xf));
+    x = imin(x, MRCZ_DPP(N, x, DPP_ROW_SHR + 4, 0xf));
+    x = imin(x, MRCZ_DPP(N, x, DPP_ROW_SHR + 8, 0xf));
+    x = imin(x, MRCZ_DPP(N, x, DPP_BCAST15, 0xa));
+    x = imin(x, MRCZ_DPP(N, x, DPP_BCAST31, 0xc));
+    return x;
 }
-__device__ __forceinline__ uint32_t wave_sum_u(uint32_t v)
-{
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
-}
+__device__ __forceinline__ int wave_min_i(int v) { return __builtin_amdgcn_readlane(wave_incl_min(v), 63); }
+__device__ __forceinline__ int wave_max_i(int v) { return __builtin_amdgcn_readlane(wave_incl_max(v), 63); }
 /* exclusive prefix sum over lanes; total returned through *total.  All 64 lanes must be active.
  * Six DPP adds (shifts inside the rows of 16 lanes, then lane 15 of a row to the next row, then lane 31 to the upper half)
  * and one scalar lane read: no LDS traffic.  The shuffle version was six ds_bpermute round trips -- most of a round of
@@ -105,23 +124,32 @@ __device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t *total)
     *total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
     return x - v;
 }
+__device__ __forceinline__ uint32_t wave_sum_u(uint32_t v)
+{
+    uint32_t total;
+    (void)wave_excl_sum(v, &total);
+    return total;
+}
 /* max over lanes strictly below this lane (neutral if none) */
 __device__ __forceinline__ int wave_excl_max(int v, int neutral)
 {
-    int l = lane_id();
-    int x = v;
-    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d); if (l >= d) x = y > x ? y : x; }
-    int e = __shfl_up(x, 1);
-    return l == 0 ? neutral : e;
+    return MRCZ_DPP(neutral, wave_incl_max(v), DPP_WAVE_SHR1, 0xf);
 }
-/* min over lanes strictly above this lane (neutral if none) */
+/* min over lanes strictly above this lane (neutral if none): suffix minima inside the rows, then the minima of the rows
+ * behind (three scalar lane reads), then the whole wave down by one lane */
 __device__ __forceinline__ int wave_excl_min_above(int v, int neutral)
 {
-    int l = lane_id();
+    constexpr int N = 0x7fffffff;
     int x = v;
-    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_down(x, d); if (l + d < 64) x = y < x ? y : x; }
-    int e = __shfl_down(x, 1);
-    return l == 63 ? neutral : e;
+    x = imin(x, MRCZ_DPP(N, x, DPP_ROW_SHL + 1, 0xf));
+    x = imin(x, MRCZ_DPP(N, x, DPP_ROW_SHL + 2, 0xf));
+    x = imin(x, MRCZ_DPP(N, x, DPP_ROW_SHL + 4, 0xf));
+    x = imin(x, MRCZ_DPP(N, x, DPP_ROW_SHL + 8, 0xf));
+    const int t1 = __builtin_amdgcn_readlane(x, 16), t2 = __builtin_amdgcn_readlane(x, 32), t3 = __builtin_amdgcn_readlane(x, 48);
+    const int m23 = imin(t2, t3), m123 = imin(t1, m23);
+    const int row = lane_id() >> 4;
+    x = imin(x, row == 0 ? m123 : row == 1 ? m23 : row == 2 ? t3 : N);
+    return MRCZ_DPP(neutral, x, DPP_WAVE_SHL1, 0xf);
 }
 
 __device__ __forceinline__ int ctz64(uint64_t x) { return __builtin_ctzll(x); }

@@ -126,7 +126,7 @@ struct LaneTile {
 __device__ __forceinline__ LaneTile analyse_lane(const uint32_t x[16], int lane, int len, uint32_t B, uint32_t F)
 {
     LaneTile lt;
-    const uint32_t pb = __shfl_up(x[15] >> 24, 1);
+    const uint32_t pb = (uint32_t)MRCZ_DPP(0, x[15] >> 24, DPP_WAVE_SHR1, 0xf); /* the last byte of the lane below (lane 0: set below) */
     uint64_t E = run_start_mask(x, pb);
     lt.V = valid_mask(len, lane);
     E |= ~lt.V;

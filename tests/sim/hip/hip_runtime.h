@@ -165,7 +165,8 @@ static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return sim_exchange(v, lane & 63); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return sim_exchange(v, 0); }
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
-/* DPP move, the controls the product uses: row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143); a lane whose row is
+/* DPP move, the controls the product uses: row_shr:n (0x110 + n), row_shl:n (0x100 + n), row_bcast:15 (0x142), row_bcast:31 (0x143),
+ * wave_shr:1 (0x138), wave_shl:1 (0x130); a lane whose row is
  * masked out or whose source does not exist keeps `old` */
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
@@ -175,7 +176,10 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     slots[L] = sim_to_bits(src);
     sim_wave_barrier();
     int from = -1;
-    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if (idx >= n) from = L - n; }
+    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if (idx >= n) from = L - n; }        /* row_shr:n */
+    else if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl - 0x100; if (idx + n <= 15) from = L + n; } /* row_shl:n */
+    else if (ctrl == 0x138) { if (L >= 1) from = L - 1; }                                                    /* wave_shr:1 */
+    else if (ctrl == 0x130) { if (L <= 62) from = L + 1; }                                                   /* wave_shl:1 */
     else if (ctrl == 0x142) { if (row >= 1) from = 16 * row - 1; }
     else if (ctrl == 0x143) { if (row >= 2) from = 31; }
     else { fprintf(stderr, "sim: DPP control 0x%x not emulated\n", ctrl); abort(); }
