@@ -630,11 +630,15 @@ struct WinScan { uint32_t myoff, total, before, stop_tid, bad, firstlit_tid, lit
 __device__ __forceinline__ WinScan window_scan(ParShared &sh, int tid, uint32_t nout, uint32_t lastlit, uint32_t flags)
 {
     const int l = lane_id(), w = tid >> 6;
-    uint32_t x = nout, ll = lastlit;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d), z = __shfl_up(ll, d);
-        if (l >= d) { x += y; if (!ll) ll = z; }
-    }
+    /* inclusive sum of the bytes and "last non-zero literal so far" over the lanes, by DPP (common.h): the shuffle version's
+     * thirteen ds_bpermute round trips were most of what the profile lists as "P3 scans" */
+    uint32_t tot_w;
+    const uint32_t x = wave_excl_sum(nout, &tot_w) + nout;
+    uint32_t ll = lastlit;
+#define MRCZ_LASTNZ(ctrl, rows) do { const uint32_t z_ = (uint32_t)MRCZ_DPP(0, ll, (ctrl), (rows)); ll = ll ? ll : z_; } while (0)
+    MRCZ_LASTNZ(DPP_ROW_SHR + 1, 0xf); MRCZ_LASTNZ(DPP_ROW_SHR + 2, 0xf); MRCZ_LASTNZ(DPP_ROW_SHR + 4, 0xf); MRCZ_LASTNZ(DPP_ROW_SHR + 8, 0xf);
+    MRCZ_LASTNZ(DPP_BCAST15, 0xa); MRCZ_LASTNZ(DPP_BCAST31, 0xc);
+#undef MRCZ_LASTNZ
     const unsigned long long bstop = __ballot((flags & (F_EOB | F_ERR)) != 0u);
     const unsigned long long bgen = __ballot((flags & F_GENERAL) != 0u), berr = __ballot((flags & F_ERR) != 0u);
     const unsigned long long blit = __ballot(lastlit != 0u);
@@ -644,8 +648,7 @@ __device__ __forceinline__ WinScan window_scan(ParShared &sh, int tid, uint32_t 
         sh.scan_d[w] = (bgen ? (uint32_t)F_GENERAL : 0u) | (berr ? (uint32_t)F_ERR : 0u) | (((w == 0 ? blit & ~1ull : blit) != 0ull) ? 0x100u : 0u);
         sh.scan_e[w] = blit ? (uint32_t)(64 * w + ctz64(blit)) : 0xffffffffu;
     }
-    uint32_t e1 = __shfl_up(ll, 1);
-    if (l == 0) e1 = 0;
+    const uint32_t e1 = (uint32_t)MRCZ_DPP(0, ll, DPP_WAVE_SHR1, 0xf); /* (lane 0: nothing before it in this wave) */
     __syncthreads();
     WinScan r;
     uint32_t pre = 0, tot = 0, prelast = 0;
