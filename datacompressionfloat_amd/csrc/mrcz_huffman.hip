@@ -740,9 +740,8 @@ __global__ __launch_bounds__(64) void k_huffman_hdr(const StreamInfo *__restrict
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const int sym = 64 * k + lane;
-        uint32_t prev = (uint32_t)__shfl_up((int)l[k], 1);
-        if (lane == 0) prev = carry_len;
-        carry_len = (uint32_t)__shfl((int)l[k], 63);
+        const uint32_t prev = (uint32_t)MRCZ_DPP(carry_len, l[k], DPP_WAVE_SHR1, 0xf); /* lane 0: the length of the symbol before the group */
+        carry_len = (uint32_t)__builtin_amdgcn_readlane((int)l[k], 63);
         st[k] = sym <= maxc + 1 && (sym == 0 || sym == maxc + 1 || l[k] != prev);
         M[k] = __ballot(st[k]);
     }
