@@ -45,6 +45,7 @@ struct mrcz_ctx {
     uint32_t lanes;                /* lanes per compress batch: 2 measured best (1: 292, 2: 306, 3: 307, 4: 229 GB/s -- with four
                                     * Huffman kernels resident their 72 KB workgroups starve the streaming kernels of LDS);
                                     * MRCZ_LANES overrides it for experiments */
+    uint32_t hist_few;             /* k_histogram: lanes that must share lane 0's first byte for a tile to count per value in the wave (MRCZ_HIST_FEW) */
     uint32_t hist_waves;           /* waves per k_histogram workgroup: 0 = by batch size (4 up to 12 chunks, else 1); MRCZ_HIST_WAVES=1|4 forces */
     int trace;                     /* MRCZ_TRACE: the synchronous calls print how long their enqueue and the wait for the device took */
     char err[256];
@@ -171,6 +172,8 @@ extern "C" int mrcz_create(mrcz_ctx_t **out, int device, uint32_t max_batch_chun
     ctx->use_hint = 1;
     ctx->huff_split = 1;
     ctx->validate_wave = 1;
+    ctx->hist_few = 16;
+    if (const char *ev = getenv("MRCZ_HIST_FEW")) { const int v = atoi(ev); if (v >= 1 && v <= 65) ctx->hist_few = (uint32_t)v; }
     if (const char *ev = getenv("MRCZ_HIST_WAVES")) { const int v = atoi(ev); if (v == 1 || v == 4) ctx->hist_waves = (uint32_t)v; }
     ctx->validate_grid = 0; /* 0 = by the batch's stream count */
     if (const char *ev = getenv("MRCZ_VALIDATE_WAVE")) ctx->validate_wave = atoi(ev) ? 1u : 0u;
@@ -359,8 +362,8 @@ static int compress_lane(mrcz_ctx *ctx, hipStream_t lstream, int phase, int slot
         if (int_mode) LAUNCH("k_tile_summary", k_tile_summary<true>, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, tsum, planes);
         else LAUNCH("k_tile_summary", k_tile_summary<false>, dim3(SPS, nb), dim3(256), bin, bfl, mask, fstart, tsum, planes);
         LAUNCH("k_stream_scan", k_stream_scan, dim3(ns), dim3(256), tsum, bfl, tinfo, sinfo, blkstart);
-        if (ctx->hist_waves ? ctx->hist_waves == 4u : nb <= 12u) LAUNCH("k_histogram", k_histogram<4>, dim3(SPS, nb, 4), dim3(256), planes, bfl, tinfo, pairhist, blkstart, slideq);
-        else LAUNCH("k_histogram", k_histogram<1>, dim3(SPS, nb, 4), dim3(64), planes, bfl, tinfo, pairhist, blkstart, slideq);
+        if (ctx->hist_waves ? ctx->hist_waves == 4u : nb <= 12u) LAUNCH("k_histogram", k_histogram<4>, dim3(SPS, nb, 4), dim3(256), planes, bfl, tinfo, pairhist, blkstart, slideq, ctx->hist_few);
+        else LAUNCH("k_histogram", k_histogram<1>, dim3(SPS, nb, 4), dim3(64), planes, bfl, tinfo, pairhist, blkstart, slideq, ctx->hist_few);
         LAUNCH("k_block_reduce", k_block_reduce, dim3(MAXBLK, ns), dim3(64), tinfo, sinfo, pairhist, blkfreq);
         LAUNCH("k_block_index", k_block_index, dim3(1), dim3(256), sinfo, ns, blkbase);
         HIPCHK(hipEventRecord(ctx->ev_stream[slot], lstream), "event"); /* this lane's streaming passes are done: the next lane may start */

@@ -318,10 +318,26 @@ __device__ __forceinline__ void load_plane_row(const uint8_t *__restrict__ pl, u
  * mostly verbatim or masked to zero) so that the tail of a (segment, chunk, plane) grid is made of short waves */
 __device__ __forceinline__ int plane_of_slot(uint32_t z) { return (int)((0x0132u >> (4u * z)) & 3u); }
 
+/* bit p of the result = byte p of the lane's 64 plane bytes (x[0] byte 0 first) equals v.  Per dword: xor with v in every byte,
+ * exact zero-byte test (bit 7 of a byte set iff the byte is zero), the four flags gathered into a nibble. */
+__device__ __forceinline__ uint64_t bytes_equal_mask(const uint32_t x[16], uint32_t v)
+{
+    const uint32_t vv = v * 0x01010101u;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t t = x[w] ^ vv;
+        const uint32_t f = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;
+        const uint32_t nib = ((f >> 7) | (f >> 14) | (f >> 21) | (f >> 28)) & 0xfu;
+        if (w < 8) lo |= nib << (4 * w); else hi |= nib << (4 * (w - 8));
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
 template <int W>
 __global__ __launch_bounds__(64 * W) void k_histogram(const uint8_t *__restrict__ planes, uint64_t nfloats,
                                                   const TileInfo *__restrict__ tinfo, uint16_t *__restrict__ pairhist,
-                                                  uint32_t *__restrict__ blkstart, uint32_t *__restrict__ slideq)
+                                                  uint32_t *__restrict__ blkstart, uint32_t *__restrict__ slideq, uint32_t few_thr)
 {
     /* one workgroup = one (segment, plane), its W waves take the segment's tiles in turn.  A tile knows its block from its
      * symbol prefix (TileInfo::P), and a segment's 32768 positions touch at most three blocks: one LDS row per block, all
@@ -401,20 +417,37 @@ __global__ __launch_bounds__(64 * W) void k_histogram(const uint8_t *__restrict_
              * first bytes) count per value in the wave first: the lanes that hold the first active lane's value are
              * found with a ballot and that lane adds their number. */
             const uint32_t b0 = x[0] & 0xffu;
-            const bool fewvalues = popc64(__ballot(b0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)b0))) >= 16;
+            const bool fewvalues = popc64(__ballot(b0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)b0))) >= (int)few_thr;
             if (fewvalues) {
+                /* Per VALUE, not per position: the value of some lane's literal at one of four probe positions is compared
+                 * with all 64 bytes of every lane at once (a byte-equality mask from dword arithmetic), the hits among the
+                 * literals not counted yet are summed over the wave and leave one atomic per block row.  Three or four
+                 * values and the tile is done; literals of values the probes did not meet go the plain way below. */
+                unsigned long long todo = L;
 #pragma unroll
-                for (int i = 0; i < 64; i++) {
-                    const bool lit = (L >> i) & 1ull;
-                    /* row B entries sit HROW words after row A */
-                    const uint32_t key = ((x[i >> 2] >> (8 * (i & 3))) & 0xffu) + (((inA >> i) & 1ull) ? 0u : (uint32_t)HROW);
-                    unsigned long long act = __ballot(lit);
+                for (int pi = 0; pi < 4; pi++) {
+                    const int i = 21 * pi; /* probe positions 0, 21, 42, 63 */
+                    unsigned long long act = __ballot((todo >> i) & 1ull);
                     while (act) {
-                        const int leader = ctz64(act);
-                        const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-                        const unsigned long long same = __ballot(lit && key == kl);
-                        if (lane == leader) atomicAdd(&rowA[kl], (uint32_t)popc64(same));
-                        act &= ~same;
+                        const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)((x[i >> 2] >> (8 * (i & 3))) & 0xffu), ctz64(act));
+                        const uint64_t hit = bytes_equal_mask(x, kl) & todo;
+                        todo &= ~hit;
+                        const uint32_t nA = wave_sum_u((uint32_t)popc64(hit & inA)), nB = wave_sum_u((uint32_t)popc64(hit & ~inA));
+                        if (lane == 0) {
+                            if (nA) atomicAdd(&rowA[kl], nA);
+                            if (nB) atomicAdd(&rowB[kl], nB);
+                        }
+                        act = __ballot((todo >> i) & 1ull);
+                    }
+                }
+                if (__ballot(todo != 0ull) != 0ull) {
+#pragma unroll
+                    for (int i = 0; i < 64; i++) {
+                        if ((todo >> i) & 1ull) {
+                            const uint32_t byte = (x[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                            uint32_t *r = ((inA >> i) & 1ull) ? rowA : rowB;
+                            atomicAdd(&r[byte], 1u);
+                        }
                     }
                 }
             } else if (__ballot(L != ~0ull || inA != ~0ull) == 0ull) {
