@@ -730,7 +730,9 @@ extern "C" int mrcz_host_malloc(mrcz_ctx_t *ctx, void **h_ptr, uint64_t bytes)
 {
     if (!ctx || !h_ptr) return MRCZ_EINVAL;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    hipError_t e = hipHostMalloc(h_ptr, (size_t)(bytes ? bytes : 16));
+    /* portable: the C host shares its pinned rings between the engines of several devices (mrcz_workers_set_devices), so the
+     * memory must be pinned for every device's context, not only for the one that is current here */
+    hipError_t e = hipHostMalloc(h_ptr, (size_t)(bytes ? bytes : 16), hipHostMallocPortable);
     return e == hipSuccess ? MRCZ_OK : fail(ctx, MRCZ_ENOMEM, "hipHostMalloc", e);
 }
 extern "C" int mrcz_host_free(mrcz_ctx_t *ctx, void *h_ptr)

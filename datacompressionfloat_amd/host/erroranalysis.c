@@ -94,6 +94,25 @@ static point_t *collect(uint64_t lo, uint64_t hi, uint32_t thr_bits, uint64_t *c
     return pts;
 }
 
+/* collect() with a candidate buffer that grows to what the range needs: the reference handles any number of NaN differences
+ * and of points that tie for the top errors (two identical files: every point ties at 0), so must this tool */
+static point_t *collect_all(uint64_t lo, uint64_t hi, uint32_t thr_bits, uint64_t *count)
+{
+    point_t *pts = collect(lo, hi, thr_bits, count);
+    if (pts) return pts;
+    const uint64_t need = *count + (*count >> 4) + 1024u; /* (the count is exact: the kernel counts what it cannot store) */
+    mrcz_dev_free(G.c, G.dp);
+    G.dp = NULL;
+    if (mrcz_dev_malloc(G.c, &G.dp, need * sizeof(point_t)) != MRCZ_OK) {
+        fprintf(stderr, "[%s:%d] ERROR: %llu candidate points do not fit in device memory\n", __FILE__, __LINE__, (unsigned long long)*count);
+        exit(-1);
+    }
+    G.cap = need;
+    pts = collect(lo, hi, thr_bits, count);
+    if (!pts) { fprintf(stderr, "[%s:%d] ERROR: candidate count changed between two passes\n", __FILE__, __LINE__); exit(-1); }
+    return pts;
+}
+
 /* prints the min(K, hi - lo) worst points of [lo, hi) (a range without NaN differences) in the reference's order; returns how many */
 static uint64_t range_topk(uint64_t lo, uint64_t hi, uint64_t K)
 {
@@ -131,7 +150,13 @@ static uint64_t range_topk(uint64_t lo, uint64_t hi, uint64_t K)
         memcpy(&tb, &thr, 4);
         pts = collect(lo, hi, tb, &count);
     }
-    if (!pts) { fprintf(stderr, "[%s:%d] ERROR: more than %llu points tie for the top errors\n", __FILE__, __LINE__, (unsigned long long)G.cap); exit(-1); }
+    if (!pts) { /* more points than the buffer holds tie for the top errors: take them all, as the reference does */
+        float thr = kth - 4e-7f;
+        if (!(thr > 0.0f)) thr = 0.0f;
+        uint32_t tb;
+        memcpy(&tb, &thr, 4);
+        pts = collect_all(lo, hi, tb, &count);
+    }
     stat_info_t *st = (stat_info_t *)malloc((size_t)count * sizeof(stat_info_t));
     if (!st) { fprintf(stderr, "[%s:%d]: Memory alloc failed\n", __FILE__, __LINE__); exit(-1); }
     qsort(pts, (size_t)count, sizeof(point_t), by_index); /* file order, as the reference's array is */
@@ -183,7 +208,8 @@ int main(int argc, char *argv[])
     if (mrcz_create(&c, device, 1) != MRCZ_OK) { fprintf(stderr, "[%s:%d] ERROR: no usable HIP device (this tool has no CPU path)\n", __FILE__, __LINE__); exit(-1); }
     G.c = c; G.f1 = f1; G.f2 = f2;
     G.B = n < (64u << 20) ? n : (64u << 20); /* floats per batch */
-    G.cap = 4u << 20;                        /* candidate records */
+    G.cap = 4u << 20;                        /* candidate records (the buffer grows when a range needs more: collect_all) */
+    if (getenv("MRCZ_ERR_CAP") && atoll(getenv("MRCZ_ERR_CAP")) > 0) G.cap = (uint64_t)atoll(getenv("MRCZ_ERR_CAP")); /* tests: force the growth path */
     CK(mrcz_dev_malloc(c, &G.d1, G.B * 4), "device memory");
     CK(mrcz_dev_malloc(c, &G.d2, G.B * 4), "device memory");
     CK(mrcz_dev_malloc(c, &G.dp, G.cap * sizeof(point_t)), "device memory");
@@ -193,7 +219,7 @@ int main(int argc, char *argv[])
      * head of the first segment, then the first NaN point, then the head of the second segment, ...  Usually there is no NaN
      * and the one segment is the whole file. */
     uint64_t nnan = 0;
-    point_t *nans = collect(0, n, 0xffffffffu, &nnan);
+    point_t *nans = collect_all(0, n, 0xffffffffu, &nnan);
     qsort(nans, (size_t)nnan, sizeof(point_t), by_index);
     uint64_t left = K, seg = 0, inan = 0;
     while (left > 0 && seg <= n) {

@@ -19,7 +19,7 @@ static void usage(char **argv) /* mrc_tar.c:82-100 */
     printf("\t-s\t data type to be converted to when compressed/decompressed, value should be [float | int], default is float\n\n");
     printf("\t-t\t operation type, e.g compress or decompressed file, value should be [zip | unzip], default is zip\n\n");
     printf("\t-g\t first HIP device to use, default 0 (extension of the MI355X build)\n\n");
-    printf("\t-G\t number of HIP devices the file's chunks are dealt to, default: all visible devices (extension of the MI355X build)\n\n");
+    printf("\t-G\t number of HIP devices the file's chunks are dealt to, default 1; 0 = all visible devices (extension of the MI355X build)\n\n");
 }
 
 static double wall_now(void)
@@ -33,7 +33,7 @@ int main(int argc, char *argv[])
 {
     const double t_main = wall_now();
     const char *in = NULL, *out = NULL, *op = "zip", *dtype = "float";
-    int bits = 0, opt, dev0 = 0, ndev = 0;
+    int bits = 0, opt, dev0 = 0, ndev = 1;
     if (argc < 2) { usage(argv); exit(-1); }
     while ((opt = getopt(argc, argv, "hi:o:b:t:s:g:G:")) != -1) {
         switch (opt) {
@@ -49,12 +49,15 @@ int main(int argc, char *argv[])
         }
     }
     if (!in || !out) { usage(argv); return -1; }
-    {   /* one file: its chunks are dealt over the GPUs of the node; -g / -G narrow that */
+    if (ndev != 1) {
+        /* -G n: the file's chunks are dealt over n GPUs of the node, -G 0 over all of them.  Opt-in: every extra
+         * device costs an engine (workspace, streams, batch buffers) inside the timed call, which one file has to be large to
+         * repay, and the path has been rehearsed on one GPU with aliased engines only (hardware scaling unmeasured). */
         const int have = mrcz_device_count();
         if (ndev <= 0) ndev = have - dev0;
         if (ndev < 1) ndev = 1;
-        mrcz_workers_set_devices(dev0, ndev);
     }
+    mrcz_workers_set_devices(dev0, ndev);
     const double t_devices = wall_now();
     printf("CODEC:mrcz-hip gfx950 (DEFLATE Z_RLE stream-compatible with ZLIB:1.2.8)\n"); /* mrc_tar.c:152 prints the zlib version */
     ctx_t ctx;

@@ -64,10 +64,19 @@ static int batch_chunks(void) /* MRCZ_BATCH_CHUNKS overrides the default (tests:
     return g_batch_chunks;
 }
 
+/* Fatal errors end the process the way the reference's do (exit(-1), workers.c:708-712) -- but die() is called from the reader,
+ * writer and pwrite threads while the other threads of the pipeline are still enqueuing copies on the session's buffers and
+ * events: running exit handlers (sessions_release_all, the HIP runtime's destructors) under them frees what they use.  So the
+ * flag stops the session teardown, stdio is flushed by hand and the process leaves through _exit with the reference's status
+ * (exit(-1) = 255). */
+static volatile int g_dying = 0;
 static void die(const char *what, mrcz_ctx_t *c)
 {
+    g_dying = 1;
     fprintf(stderr, "[%s:%d] ERROR: %s: %s\n", __FILE__, __LINE__, what, c ? mrcz_last_error(c) : "");
-    exit(-1);
+    fflush(stdout);
+    fflush(stderr);
+    _exit(255);
 }
 #define CK(call, what, c) do { if ((call) != MRCZ_OK) die(what, c); } while (0)
 
@@ -186,6 +195,7 @@ static void session_release(void *p)
 /* orderly exit (a host program that links the library and returns from main): give the pinned rings and device buffers back */
 static void sessions_release_all(void)
 {
+    if (g_dying) return; /* an error exit: threads may still be using the sessions (see die()) */
     for (int d = 0; d < MAXDEV; d++)
         for (int i = 0; i < SESSIONS_PER_DEV; i++) session_release(&g_ses[d][i]);
 }
@@ -477,7 +487,9 @@ static void *reader_main(void *arg)
                     pay += l;
                 }
                 bytes = 16 + pay;
-                if (bytes > IN_SLOT) die("chunk record larger than a chunk of RAW planes", NULL);
+                /* the largest record the reference's writer can emit: a plane that does not shrink is stored RAW (zip.c:177-190),
+                 * so four RAW planes of this chunk's floats; anything longer would also overrun the device batch buffer */
+                if (bytes > 16u + 4u * nfl || bytes > IN_SLOT) die("chunk record larger than a chunk of RAW planes", NULL);
                 if (map) {
                     if (mpos + bytes > msize) die("truncated container (payload)", NULL);
                     h = map + mpos;
@@ -494,6 +506,7 @@ static void *reader_main(void *arg)
             mpos += bytes;
             if (done_floats >= p->total_floats) eof = 1;
             if (!map || fillers) p->t_fread += now_sec() - tt;
+            if (off + bytes > D->d_a_cap) die("batch larger than its device buffer", NULL);
             CK(mrcz_copy_h2d_async(c, MRCZ_STREAM_UPLOAD, (char *)D->d_a[b] + off, h, bytes), "H2D copy", c);
             if (map && !fillers) p->t_fread += now_sec() - tt; /* a copy from pageable memory returns when the source has been consumed */
             else { CK(mrcz_event_record(c, MRCZ_STREAM_UPLOAD, D->in_ev[slot]), "event record", c); s->in_dev[slot] = di; }

@@ -125,6 +125,7 @@ static inline void __threadfence_block() {}
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+#define hipHostMallocPortable 0x1u
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return hipSuccess; }
 template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipHostMalloc((void **)p, n, f); }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }

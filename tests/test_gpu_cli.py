@@ -268,3 +268,31 @@ def test_mrc_tar_decodes_lz4_containers(tmp_path):
     r = _run([exe, "-i", os.path.join(util.GOLDEN, "lz4hc_poisson.zip"), "-o", str(out), "-t", "unzip"])
     assert r.returncode == 0, r.stderr
     assert out.read_bytes() == data
+
+
+def test_damaged_containers_end_with_an_error_status_not_a_signal(tmp_path):
+    """exit(-1) semantics of the reference (workers.c:708-712) when the error is raised by a pipeline thread while the others still
+    use the session's pinned rings, device buffers and events: a plain non-zero status, never a signal out of an exit handler.
+    Then one orderly run with MRCZ_FULL_TEARDOWN=1 (the sessions are released through atexit) must give the same bytes as the
+    fast-exit path."""
+    from test_host_sim import _damaged_containers
+    exe, exex = os.path.join(BIN, "mrc_tar"), os.path.join(BIN, "mrc_tarx")
+    w = util.gauss_words(util.CHUNK + 60000, seed=5)
+    src, z, z2 = tmp_path / "in.mrc", tmp_path / "o.zip", tmp_path / "o2.zip"
+    src.write_bytes(w.tobytes())
+    assert _run([exe, "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip"]).returncode == 0
+    good = z.read_bytes()
+    for what, bad in _damaged_containers(good).items():
+        b = tmp_path / "bad.zip"
+        b.write_bytes(bad)
+        r = _run([exe, "-i", str(b), "-o", str(tmp_path / "x.mrc"), "-t", "unzip"])
+        assert r.returncode > 0 and "ERROR" in r.stderr, (what, r.returncode, r.stderr)
+        lst = tmp_path / "l.txt"
+        lst.write_text(str(b) + "\n")
+        r = _run([exex, "-i", str(lst), "-t", "unzip", "-o", str(tmp_path), "-n", "2"])
+        assert r.returncode > 0, (what, r.returncode, r.stderr)
+    env = dict(os.environ, MRCZ_FULL_TEARDOWN="1")
+    assert _run([exe, "-i", str(src), "-o", str(z2), "-b", "8", "-t", "zip"], env=env).returncode == 0
+    assert z2.read_bytes() == good
+    r = _run([exe, "-i", str(z2), "-o", str(tmp_path / "ok.mrc"), "-t", "unzip"], env=env)
+    assert r.returncode == 0 and (tmp_path / "ok.mrc").read_bytes() == util.erase_expected(w, 8).tobytes()

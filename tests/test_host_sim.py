@@ -104,17 +104,77 @@ def test_one_file_dealt_over_two_devices(simbin, oracle, tmp_path):
     src, z, back = tmp_path / "in.mrc", tmp_path / "o.zip", tmp_path / "b.mrc"
     src.write_bytes(w.tobytes())
     env = {"SIM_DEVICES": "2", "MRCZ_BATCH_CHUNKS": "1", "MRCZ_TRACE": "1"}
-    r = _run([simbin["mrc_tar"], "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip"], env=env)
+    r = _run([simbin["mrc_tar"], "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip", "-G", "0"], env=env)   # -G 0: all visible devices
     assert r.returncode == 0, r.stderr
     assert r.stderr.count("mrcz_create") == 2, r.stderr          # two engines were brought up
     ref = oracle.compress(w.tobytes(), 8, threads=3)
     assert z.read_bytes() == ref
-    r = _run([simbin["mrc_tar"], "-i", str(z), "-o", str(back), "-t", "unzip"], env=env)
+    r = _run([simbin["mrc_tar"], "-i", str(z), "-o", str(back), "-t", "unzip", "-G", "2"], env=env)
     assert r.returncode == 0, r.stderr
     assert back.read_bytes() == util.erase_expected(w, 8).tobytes()
-    # one device only (-G 1): the same bytes
-    r = _run([simbin["mrc_tar"], "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip", "-G", "1"], env=env)
+    # one device only (the default, several devices are opt-in): the same bytes
+    r = _run([simbin["mrc_tar"], "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip"], env=env)
     assert r.returncode == 0 and r.stderr.count("mrcz_create") == 1 and z.read_bytes() == ref
+
+
+def test_four_devices_and_a_short_last_batch(simbin, oracle, tmp_path):
+    """Four emulated devices, one chunk per batch, five chunks: the batches wrap around the devices (device 0 codes batches 0
+    and 4 in its two buffers), the last batch is a partial chunk, and the records come back in file order."""
+    n = 4 * util.CHUNK + 4097
+    w = np.zeros(n, np.uint32)
+    w[:256] = util.kat_words(256)
+    for c in range(5):                               # a noisy stretch in every chunk so that the five records differ
+        a = c * util.CHUNK + 300 * (c + 1)
+        m = min(3000, n - a)
+        w[a: a + m] = util.gauss_words(3000, seed=30 + c, header=False)[:m]
+    src, z, back = tmp_path / "in.mrc", tmp_path / "o.zip", tmp_path / "b.mrc"
+    src.write_bytes(w.tobytes())
+    env = {"SIM_DEVICES": "4", "MRCZ_BATCH_CHUNKS": "1", "MRCZ_TRACE": "1"}
+    r = _run([simbin["mrc_tar"], "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip", "-G", "4"], env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("mrcz_create") == 4, r.stderr
+    ref = oracle.compress(w.tobytes(), 8, threads=5)
+    assert z.read_bytes() == ref
+    r = _run([simbin["mrc_tar"], "-i", str(z), "-o", str(back), "-t", "unzip", "-G", "4"], env=env)
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == util.erase_expected(w, 8).tobytes()
+
+
+def _damaged_containers(z: bytes):
+    """a container cut inside its second chunk header / inside a payload, one whose first deflate stream is garbage, and one
+    whose chunk header announces more bytes than four RAW planes can have"""
+    h = np.frombuffer(z[17:33], "<u4")
+    first_len = int(h[0] & 0x7fffffff)
+    garbage = bytearray(z)
+    garbage[33: 33 + min(first_len, 64)] = bytes((37 * i + 11) & 0xff for i in range(min(first_len, 64)))
+    huge = bytearray(z)
+    huge[17:21] = (0x7fffffff).to_bytes(4, "little")
+    return {"cut in a chunk header": z[:17 + 7], "cut in a payload": z[: len(z) - len(z) // 3], "garbage deflate stream": bytes(garbage),
+            "record longer than RAW planes": bytes(huge)}
+
+
+def test_damaged_containers_end_with_an_error_status_not_a_signal(simbin, tmp_path):
+    """The reference leaves with exit(-1) on what it cannot handle (workers.c:708-712); here the error is raised by a pipeline
+    thread while the others still use the session: the process must end with a plain non-zero status (no SIGSEGV / SIGABRT
+    out of the exit handlers), for mrc_tar and for a worker thread of mrc_tarx."""
+    w = util.gauss_words(60000, seed=5)
+    src, z = tmp_path / "in.mrc", tmp_path / "o.zip"
+    src.write_bytes(w.tobytes())
+    assert _run([simbin["mrc_tar"], "-i", str(src), "-o", str(z), "-b", "8", "-t", "zip"]).returncode == 0
+    good = z.read_bytes()
+    for what, bad in _damaged_containers(good).items():
+        b = tmp_path / "bad.zip"
+        b.write_bytes(bad)
+        r = _run([simbin["mrc_tar"], "-i", str(b), "-o", str(tmp_path / "x.mrc"), "-t", "unzip"])
+        assert r.returncode > 0, (what, r.returncode, r.stderr)          # > 0: an exit status; < 0 would be a signal
+        assert "ERROR" in r.stderr, (what, r.stderr)
+        lst = tmp_path / "l.txt"
+        lst.write_text(str(b) + "\n")
+        r = _run([simbin["mrc_tarx"], "-i", str(lst), "-t", "unzip", "-o", str(tmp_path), "-n", "2"])
+        assert r.returncode > 0, (what, r.returncode, r.stderr)
+    # the orderly path still releases its sessions: one good run with the full teardown
+    r = _run([simbin["mrc_tar"], "-i", str(z), "-o", str(tmp_path / "ok.mrc"), "-t", "unzip"], env={"MRCZ_FULL_TEARDOWN": "1"})
+    assert r.returncode == 0 and (tmp_path / "ok.mrc").read_bytes() == util.erase_expected(w, 8).tobytes()
 
 
 @pytest.mark.skipif(util.ref_binary("erroranalysis_c") is None, reason="oracle/_ref not built (needs /root/reference)")
@@ -140,3 +200,24 @@ def test_erroranalysis_matches_the_reference_tool(simbin, tmp_path, k, nanat):
     assert mine.returncode == 0 and theirs.returncode == 0, (mine.stderr, theirs.stderr)
     assert mine.stdout == theirs.stdout, (mine.stdout, theirs.stdout)
     assert len(mine.stdout.splitlines()) == k
+
+
+@pytest.mark.skipif(util.ref_binary("erroranalysis_c") is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_erroranalysis_with_more_ties_and_nans_than_the_candidate_buffer(simbin, tmp_path):
+    """The reference's tool takes any number of NaN differences and of points that tie for the top error (two identical
+    files: every point ties at 0).  With the candidate buffer forced down to 64 records both must go through its growth
+    path and still print the reference's lines."""
+    ref = util.ref_binary("erroranalysis_c")
+    w = util.gauss_words(20000, seed=3)
+    a, b, c = tmp_path / "a.bin", tmp_path / "b.bin", tmp_path / "c.bin"
+    a.write_bytes(w.tobytes())
+    b.write_bytes(w.tobytes())                              # identical: 20000 points tie
+    d = util.erase_expected(w, 12)
+    f = d.view(np.float32)
+    f[500:20000:97] = np.float32(np.nan)                    # 202 NaN walls
+    c.write_bytes(d.tobytes())
+    for other, k in ((b, 4), (c, 6)):
+        mine = _run([simbin["erroranalysis"], "-a", str(a), "-b", str(other), "-k", str(k)], env={"MRCZ_ERR_CAP": "64"})
+        theirs = _run([ref, "-a", str(a), "-b", str(other), "-k", str(k)])
+        assert mine.returncode == 0 and theirs.returncode == 0, (mine.stderr, theirs.stderr)
+        assert mine.stdout == theirs.stdout, (mine.stdout, theirs.stdout)
