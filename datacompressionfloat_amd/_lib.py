@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmrcz_hip.so")
+# MRCZ_LIB_PATH: developer knob (tools/ab_*.py time several builds of the kernels in one GPU call); it still is a HIP build
+LIB_PATH = os.environ.get("MRCZ_LIB_PATH") or os.path.join(_HERE, "lib", "libmrcz_hip.so")
 
 
 class MrczLibraryMissing(ImportError):

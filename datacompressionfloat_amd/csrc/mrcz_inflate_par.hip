@@ -378,11 +378,98 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
         sh.ring[q][tid] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (ex[3] << 24); /* positions kbase + 4q .. + 3 */
     }
 }
+#ifndef MRCZ_P1_PIPE
+#define MRCZ_P1_PIPE 1
+#endif
+/* The same recurrence, software-pipelined.  A group of four positions needs two LDS round trips -- the token bits of its four
+ * positions (table), then the exits those land on (ring) -- and only the second one depends on the groups before it.  So the
+ * table bytes of group g - 1 are requested before the ring reads of group g are issued: one round trip per group instead of
+ * two on the lane's critical path (the compiler cannot do that itself: it must assume the ring stores alias the table).  The
+ * window dwords of the next word are fetched a whole word ahead for the same reason. */
+__device__ __forceinline__ unsigned long long piece_word_bits(const ParShared &sh, uint32_t tid, int wq, uint32_t lead, uint32_t nw)
+{
+    const uint32_t wi0 = tid * nw + (uint32_t)wq;
+    const uint32_t wp0 = sh.win[WSK(wi0)], wp1 = sh.win[WSK(wi0 + 1u)], wp2 = sh.win[WSK(wi0 + 2u)];
+    const unsigned long long a01 = ((unsigned long long)wp1 << 32) | wp0, a12 = ((unsigned long long)wp2 << 32) | wp1;
+    return ((a12 >> lead) << 32) | (uint32_t)(a01 >> lead);
+}
+/* byte offset into ParShared::tok of the entry for the LBITS stream bits at position sft (0..31) of the funnelled word */
+__device__ __forceinline__ uint32_t tok_byte_off(unsigned long long w01, int sft)
+{
+    return sft >= 2 ? (uint32_t)(w01 >> (sft - 2)) & (((1u << LBITS) - 1u) << 2) : (uint32_t)((w01 << 2) >> sft) & (((1u << LBITS) - 1u) << 2);
+}
+template <bool TAIL, bool MIN4, bool COMPLETE>
+__device__ __forceinline__ void piece_exit_word_pipe(ParShared &sh, uint32_t tid, int wq, uint32_t nw, unsigned long long w01,
+                                                     unsigned long long wnext /* the word below (wq - 1), valid when wq > 0 */, uint32_t tt[4] /* in: table bytes of this word's group 7; out: of the next word's */)
+{
+    const uint8_t *tokb = reinterpret_cast<const uint8_t *>(sh.tok);
+    const uint8_t *ringb = reinterpret_cast<const uint8_t *>(&sh.ring[0][0]);
+    const uint32_t lane4 = tid << 2;
+#pragma unroll
+    for (int q = 7; q >= 0; q--) {
+        uint32_t tn[4] = {0, 0, 0, 0};
+        if (q > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) tn[j] = tokb[tok_byte_off(w01, 4 * (q - 1) + j)];
+        } else if (wq > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) tn[j] = tokb[tok_byte_off(wnext, 28 + j)];
+        }
+        if (!TAIL) sh.ring[(q + 7) & 7][tid] = X_STOP * 0x01010101u; /* (see piece_exit_word) */
+        if (!COMPLETE) {
+            if ((tt[0] == 0u) | (tt[1] == 0u) | (tt[2] == 0u) | (tt[3] == 0u)) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (tt[j] == 0u) tt[j] = token_bits(sh, w01 >> (4 * q + j));
+            }
+        }
+        uint32_t ex[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            /* ring_off(position + token bits); the word's base (a multiple of 32) falls outside the mask */
+            const uint32_t c = (uint32_t)(4 * q + j) * 0x201u;
+            ex[j] = ringb[((tt[j] * 0x201u + c) & 0x3803u) | lane4];
+        }
+        if (TAIL) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t x = 32u * (uint32_t)wq + (uint32_t)(4 * q + j) + tt[j];
+                ex[j] = tt[j] >= X_STOP ? X_STOP : (x >= 32u * nw ? x - 32u * nw : ex[j]);
+            }
+        }
+        if (!MIN4) {
+            if (tt[2] == 1u) ex[2] = ex[3];
+            if (tt[1] == 1u) ex[1] = ex[2];
+            if (tt[1] == 2u) ex[1] = ex[3];
+            if (tt[0] == 1u) ex[0] = ex[1];
+            if (tt[0] == 2u) ex[0] = ex[2];
+            if (tt[0] == 3u) ex[0] = ex[3];
+        }
+        sh.ring[q][tid] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (ex[3] << 24);
+#pragma unroll
+        for (int j = 0; j < 4; j++) tt[j] = tn[j];
+    }
+}
 template <bool MIN4, bool COMPLETE>
 __device__ __forceinline__ void piece_exit_lds(ParShared &sh, uint32_t tid, uint32_t lead, uint32_t nw)
 {
+#if MRCZ_P1_PIPE
+    const uint8_t *tokb = reinterpret_cast<const uint8_t *>(sh.tok);
+    unsigned long long w = piece_word_bits(sh, tid, (int)nw - 1, lead, nw);
+    unsigned long long wn = nw > 1u ? piece_word_bits(sh, tid, (int)nw - 2, lead, nw) : 0ull;
+    uint32_t tt[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) tt[j] = tokb[tok_byte_off(w, 28 + j)];
+    piece_exit_word_pipe<true, MIN4, COMPLETE>(sh, tid, (int)nw - 1, nw, w, wn, tt);
+    for (int wq = (int)nw - 2; wq >= 0; wq--) {
+        w = wn;
+        wn = wq > 0 ? piece_word_bits(sh, tid, wq - 1, lead, nw) : 0ull;
+        piece_exit_word_pipe<false, MIN4, COMPLETE>(sh, tid, wq, nw, w, wn, tt);
+    }
+#else
     piece_exit_word<true, MIN4, COMPLETE>(sh, tid, (int)nw - 1, lead, nw);
     for (int wq = (int)nw - 2; wq >= 0; wq--) piece_exit_word<false, MIN4, COMPLETE>(sh, tid, wq, lead, nw);
+#endif
 }
 
 
@@ -481,14 +568,222 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
     return r;
 }
 
+constexpr uint32_t WG_LIT = 1u << 17; /* walk_general_token / count_general_token: the token is a literal, byte << 18 */
+/* ---- branch-lean walks ------------------------------------------------------------------------------------------------
+ * The walks above are written as a lane would run them alone: a loop with a handful of nested ifs.  A wave turns every one of
+ * those ifs into an exec-mask region (s_and_saveexec, a branch, s_or exec), ten or more per token, and the kernel's counters
+ * showed it: one scalar and 0.15 branch instructions for every two vector ones, the walks two to five times longer than their
+ * arithmetic.  The lean forms keep ALL lanes in one straight-line body per step -- a lane that has nothing to do advances by
+ * zero bits -- with selects instead of ifs, one wave-uniform branch for the loop and one (rarely taken) for the tokens the
+ * table does not resolve. */
+struct BitWin {       /* a lane's view of the staged window: dwords wi, wi + 1 (lo, hi) and wi + 2 (nxt) */
+    uint32_t lo, hi, nxt, wi, bo; /* bo = bit offset of the position inside lo (< 32) */
+};
+__device__ __forceinline__ void bw_init(BitWin &b, const ParShared &sh, uint32_t pos)
+{
+    b.wi = pos >> 5; b.bo = pos & 31u;
+    b.lo = sh.win[WSK(b.wi)]; b.hi = sh.win[WSK(b.wi + 1u)]; b.nxt = sh.win[WSK(b.wi + 2u)];
+}
+__device__ __forceinline__ uint32_t bw_peek(const BitWin &b) { return __builtin_amdgcn_alignbit(b.hi, b.lo, b.bo); } /* 32 bits from the position */
+__device__ __forceinline__ void bw_skip(BitWin &b, const ParShared &sh, uint32_t t /* < 32 */)
+{
+    b.bo += t;
+    const bool adv = b.bo >= 32u;
+    b.lo = adv ? b.hi : b.lo;
+    b.hi = adv ? b.nxt : b.hi;
+    b.wi += adv ? 1u : 0u;
+    b.bo -= adv ? 32u : 0u;
+    b.nxt = sh.win[WSK(b.wi + 2u)]; /* (every step, no test: its address does not wait for anything but wi) */
+}
+/* A token the table leaves to the slow path (code longer than the index, END_BLOCK, a match whose fields do not fit, other
+ * distances), for the counting walks: bits | bytes << 8 | literal << 17 (WG_LIT | byte << 18) | CG_STOP when the lane's walk ends
+ * here; *flags collects F_EOB / F_ERR / F_GENERAL exactly as count_walk() does. */
+constexpr uint32_t CG_STOP = 1u << 31;
+__device__ __noinline__ uint32_t count_general_token(const ParShared &sh, uint32_t pos, uint32_t *flags)
+{
+    auto peek = [&](uint32_t p) -> uint32_t {
+        const uint32_t i = p >> 5;
+        return (uint32_t)((((unsigned long long)sh.win[WSK(i + 1u)] << 32) | sh.win[WSK(i)]) >> (p & 31u));
+    };
+    const uint32_t d = huff_decode_lit(sh, peek(pos));
+    if (d == 0xffffffffu) { *flags |= F_ERR; return CG_STOP; }
+    const uint32_t l = d >> 16, sym = d & 0xffffu;
+    if (sym < 256u) return l | (1u << 8) | WG_LIT | (sym << 18);
+    if (sym == 256u) { *flags |= F_EOB; return l | CG_STOP; }
+    const int lc = (int)sym - 257;
+    if (lc >= 29) { *flags |= F_ERR; return CG_STOP; }
+    const uint32_t xb = (uint32_t)len_extra_bits(lc);
+    const uint32_t ml = base_len_of(lc) + (peek(pos + l) & ((1u << xb) - 1u));
+    const uint32_t dbits = peek(pos + l + xb);
+    if (!sh.dist.lut[dbits & ((1u << DBITS) - 1u)]) { *flags |= F_ERR; return CG_STOP; } /* distance code beyond the fast table */
+    const uint32_t dd = huff_decode_dist(sh.dist, dbits);
+    if (dd == 0xffffffffu || (dd & 0xffffu) >= 30u) { *flags |= F_ERR; return CG_STOP; }
+    const uint32_t dl = dd >> 16, dc = dd & 0xffffu;
+    const uint32_t dxb = dc < 4u ? 0u : (dc >> 1) - 1u;
+    if (l + xb + dl + dxb > (uint32_t)MAXTOK) { *flags |= F_ERR; return CG_STOP; }
+    const uint32_t dist = base_dist_of((int)dc) + (peek(pos + l + xb + dl) & ((1u << dxb) - 1u));
+    if (dist != 1u) *flags |= F_GENERAL;
+    return (l + xb + dl + dxb) | (ml << 8);
+}
+
+/* P3, lean: every lane of the wave calls it (a lane without a piece passes limit = 0); same results as count_walk<TRACK_LAST, false, DBL>. */
+template <bool TRACK_LAST, bool DBL>
+__device__ __forceinline__ SubResult count_walk_lean(const ParShared &sh, uint32_t start, uint32_t limit)
+{
+    SubResult r;
+    r.nout = 0; r.flags = 0; r.lastlit = 0;
+    uint32_t pos = start;
+    BitWin b;
+    bw_init(b, sh, pos);
+    while (__ballot(pos < limit) != 0ull) {
+        const bool act = pos < limit;
+        const uint32_t e = sh.tok[bw_peek(b) & ((1u << LBITS) - 1u)];
+        uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu, lit = (e >> TOK_SYM_SHIFT) & 0xffu;
+        bool islit = n == 1u;
+        if (DBL) {
+            const bool pair = (e & TOK_PAIR) != 0u;
+            const bool both = pair && pos + t < limit; /* the second literal starts inside this piece: both in one step */
+            n = pair ? (both ? 2u : 1u) : n;
+            lit = both ? (e >> 9) & 0xffu : lit;
+            t += both ? (e >> TOK_LEN_SHIFT) & 15u : 0u;
+            islit = islit || pair;
+        }
+        const bool fast = t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1;
+        bool go = act && fast;
+        if (__ballot(act && !fast) != 0ull) { /* rare */
+            if (act && !fast) {
+                const uint32_t g = count_general_token(sh, pos, &r.flags);
+                t = g & 0xffu; n = (g >> 8) & 0x1ffu; lit = (g >> 18) & 0xffu; islit = (g & WG_LIT) != 0u;
+                go = true;
+                if (g & CG_STOP) { n = 0u; islit = false; limit = 0u; } /* END_BLOCK: its bits still count (r.land is just past it) */
+                if (r.flags & F_ERR) t = 0u;
+            }
+        }
+        t = go ? t : 0u;
+        r.nout += go ? n : 0u;
+        if (TRACK_LAST) r.lastlit = (go && islit) ? (0x100u | lit) : r.lastlit;
+        pos += t;
+        bw_skip(b, sh, t);
+    }
+    r.land = pos;
+    return r;
+}
+
+/* P3 for blocks of long codes (a mantissa plane: every token a literal of 7..9 bits, a match once in a few thousand): the count
+ * walk KEEPS what it decodes.  A piece of 256 bits holds at most 37 such tokens; their bytes go, four at a time, into the lane's
+ * column of ParShared::ring (dead once the entries are known: 32 bytes per lane) and the ninth dword stays in a register.  The
+ * window's bytes are then written from there (staged_copy_out) and the second walk over the same bits -- half of the table
+ * look-ups of such a block -- is not made.  A lane that meets a match, a 37th literal or anything the table does not resolve
+ * gives up staging (STG_SLOW) and takes the write walk as before. */
+constexpr uint32_t STG_CAP = 36u, STG_SLOW = 0x80000000u;
+struct Staged { uint32_t cnt /* literals staged, | STG_SLOW */, w9 /* the word being filled: bytes (cnt & ~3) .. cnt - 1 in its TOP bytes */; };
+__device__ __forceinline__ SubResult stage_walk(ParShared &sh, uint32_t start, uint32_t limit, int tid, Staged &sg)
+{
+    SubResult r;
+    r.nout = 0; r.flags = 0; r.lastlit = 0;
+    uint32_t pos = start;
+    uint32_t wi = pos >> 5;
+    uint64_t buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
+    int nb = 64 - (int)(pos & 31u);
+    wi += 2;
+    uint32_t cnt = 0, accw = 0, slow = 0;
+    while (pos < limit) {
+        if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
+        const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
+        const uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
+        if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) {
+            buf >>= t; nb -= (int)t; pos += t;
+            r.nout += n;
+            if (n == 1u) {
+                const uint32_t lit = (e >> TOK_SYM_SHIFT) & 0xffu;
+                r.lastlit = 0x100u | lit;
+                if (cnt < STG_CAP) {
+                    accw = (accw >> 8) | (lit << 24);
+                    cnt++;
+                    if ((cnt & 3u) == 0u && cnt <= 32u) sh.ring[(cnt >> 2) - 1u][tid] = accw;
+                } else slow = STG_SLOW;
+            } else slow = STG_SLOW;
+            continue;
+        }
+        /* general path: long codes, END_BLOCK, other distances, errors (as count_walk) */
+        slow = STG_SLOW;
+        const uint32_t d = huff_decode_lit(sh, (uint32_t)buf);
+        if (d == 0xffffffffu) { r.flags |= F_ERR; break; }
+        const int l = (int)(d >> 16);
+        const uint32_t sym = d & 0xffffu;
+        buf >>= l; nb -= l; pos += (uint32_t)l;
+        if (sym < 256u) {
+            r.nout++;
+            r.lastlit = 0x100u | sym;
+        } else if (sym == 256u) {
+            r.flags |= F_EOB;
+            break;
+        } else {
+            const int lc = (int)sym - 257;
+            if (lc >= 29) { r.flags |= F_ERR; break; }
+            const int xb = len_extra_bits(lc);
+            const uint32_t ml = base_len_of(lc) + ((uint32_t)buf & ((1u << xb) - 1u));
+            buf >>= xb; nb -= xb; pos += (uint32_t)xb;
+            if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
+            if (!sh.dist.lut[(uint32_t)buf & ((1u << DBITS) - 1u)]) { r.flags |= F_ERR; break; }
+            const uint32_t dd = huff_decode_dist(sh.dist, (uint32_t)buf);
+            if (dd == 0xffffffffu || (dd & 0xffffu) >= 30u) { r.flags |= F_ERR; break; }
+            const int dl = (int)(dd >> 16), dc = (int)(dd & 0xffffu);
+            buf >>= dl; nb -= dl; pos += (uint32_t)dl;
+            const int dxb = dc < 4 ? 0 : (dc >> 1) - 1;
+            if (l + xb + dl + dxb > MAXTOK) { r.flags |= F_ERR; break; }
+            const uint32_t dist = base_dist_of(dc) + ((uint32_t)buf & ((1u << dxb) - 1u));
+            buf >>= dxb; nb -= dxb; pos += (uint32_t)dxb;
+            if (dist != 1u) r.flags |= F_GENERAL;
+            r.nout += ml;
+        }
+    }
+    r.land = pos;
+    sg.cnt = cnt | slow;
+    sg.w9 = accw;
+    return r;
+}
+/* the staged bytes of one lane (sg.cnt of them, no STG_SLOW) to `out`: whole dwords from the ring column (the ninth from the
+ * register), 16 bytes at a time where they are there, then the last one to three bytes */
+__device__ __forceinline__ void pk_store4(uint8_t *p, uint32_t w);
+__device__ __forceinline__ void staged_copy_out(const ParShared &sh, int tid, const Staged &sg, uint8_t *out)
+{
+    const uint32_t cnt = sg.cnt, nfull = cnt >> 2;
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = sh.ring[i][tid];
+    if (nfull >= 4u) { const uint4 v = make_uint4(w[0], w[1], w[2], w[3]); __builtin_memcpy(out, &v, 16); }
+    else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) if ((uint32_t)i < nfull) pk_store4(out + 4 * i, w[i]);
+    }
+    if (nfull >= 8u) { const uint4 v = make_uint4(w[4], w[5], w[6], w[7]); __builtin_memcpy(out + 16, &v, 16); }
+    else {
+#pragma unroll
+        for (int i = 4; i < 7; i++) if ((uint32_t)i < nfull) pk_store4(out + 4 * i, w[i]);
+    }
+    if (nfull >= 9u) pk_store4(out + 32, sg.w9);
+    const uint32_t k = cnt & 3u;
+    if (k) {
+        const uint32_t tail = sg.w9 >> (8u * (4u - k)); /* the k newest bytes sit in the top of the word */
+        for (uint32_t j = 0; j < k; j++) out[4u * nfull + j] = (uint8_t)(tail >> (8u * j));
+    }
+}
+
 /* one (generally unaligned) dword store: gfx9 global memory takes unaligned dword accesses */
-__device__ __forceinline__ void pk_store4(uint8_t *p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
+#ifndef EXP_NOSTORE
+#define EXP_NOSTORE 0
+#endif
+__device__ __forceinline__ void pk_store4(uint8_t *p, uint32_t w)
+{
+    if (EXP_NOSTORE) { asm volatile("" :: "v"(w), "v"(p)); return; } /* what-if timing builds only: everything but the store itself */
+    __builtin_memcpy(p, &w, 4);
+}
 
 /* A token the table does not resolve in one look-up (code longer than the index, match whose fields do not fit, END_BLOCK),
  * decoded straight from the staged window at bit `pos`: bits | bytes produced << 8 | (literal: 1 << 17 | byte << 18);
  * 0 = the walk ends here (END_BLOCK or an error the count walk has already reported).  Rare, so kept out of line: the walk
  * loops stay small and keep their registers. */
-constexpr uint32_t WG_LIT = 1u << 17;
 __device__ __noinline__ uint32_t walk_general_token(const ParShared &sh, uint32_t pos)
 {
     auto peek = [&](uint32_t p) -> uint32_t { /* >= 32 bits from window bit p */
@@ -512,10 +807,14 @@ __device__ __noinline__ uint32_t walk_general_token(const ParShared &sh, uint32_
 }
 
 /* P4 walk of one lane: decode its piece from `start` and write the plane bytes at `out`.  Every token is "n copies of the
- * last literal" (n = 1 and a new last literal for a literal token, 3..258 for a distance-1 match), appended four bytes at a
- * time into a 64-bit register and stored with (generally unaligned) dword stores -- gfx9 global memory takes them.  One code
- * path for literals and runs: the lanes of a wave, which hold different token kinds in every iteration, do not serialise
- * through two branches. */
+ * last literal" (n = 1 and a new last literal for a literal token, 3..258 for a distance-1 match).
+ *
+ * ONE flat loop: an iteration fetches the next token if the current run is used up, then appends up to eight bytes of the run
+ * to a 64-bit register and stores the dwords that are complete ((generally unaligned) dword stores -- gfx9 global memory takes
+ * them; whole 16-byte stores while a long run lasts).  The version before this one had the byte loops nested inside the token
+ * loop, and a wave ran every inner loop as long as its longest lane: with the geometric run lengths of an exponent plane that
+ * was four to five inner iterations per token instead of the one a lane needs on average (measured, 1 GiB b = 8: the write
+ * walks of the short-code blocks alone were 0.37 ms of the kernel's 2.36). */
 template <bool DBL>
 __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, uint32_t limit, uint8_t *out, uint32_t last)
 {
@@ -524,58 +823,57 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
     uint64_t buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
     int nb = 64 - (int)(pos & 31u);
     wi += 2;
-    uint8_t *p = out;            /* where the low byte of acc goes */
-    unsigned long long acc = 0;  /* pending bytes */
-    uint32_t fill = 0;           /* bytes held in acc (< 4 at the top of the loop) */
-    while (pos < limit) {
-        if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
-        const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
-        uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
-        uint32_t pair = 0; /* two literals taken in one step: first | second << 8 */
-        if (DBL) {
-            const uint32_t l2 = tok_second_len(e);
-            if (l2) {
-                n = 1u;
-                if (pos + t < limit) { t += l2; n = 2u; pair = ((e >> TOK_SYM_SHIFT) & 0xffu) | (((e >> 9) & 0xffu) << 8) | 0x10000u; }
+    uint8_t *p = out;             /* where the low byte of acc goes */
+    unsigned long long acc = 0;   /* pending bytes */
+    uint32_t fill = 0;            /* bytes held in acc (< 4 at the top of the loop) */
+    uint32_t rem = 0;             /* bytes of the current run not appended yet */
+    uint32_t pat = 0;             /* what the run repeats: its byte in all four positions (two literals taken in one step: first | second << 8) */
+    for (;;) {
+        if (rem == 0u) {
+            if (pos >= limit) break;
+            if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
+            const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
+            uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
+            bool pair = false;
+            if (DBL) {
+                const uint32_t l2 = tok_second_len(e);
+                if (l2) {
+                    n = 1u;
+                    if (pos + t < limit) { t += l2; n = 2u; pair = true; }
+                }
             }
-        }
-        if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) {
-            if (n == 1u) last = (e >> TOK_SYM_SHIFT) & 0xffu;
-            if (DBL && pair) last = (pair >> 8) & 0xffu;
-            buf >>= t; nb -= (int)t; pos += t;
-        } else {
-            const uint32_t g = walk_general_token(sh, pos);
-            if (g == 0u) break;
-            t = g & 0xffu; n = (g >> 8) & 0x1ffu;
-            if (g & WG_LIT) last = (g >> 18) & 0xffu;
-            pos += t;
-            wi = pos >> 5;
-            buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
-            nb = 64 - (int)(pos & 31u);
-            wi += 2;
-        }
-        const uint32_t pat = (DBL && pair) ? (pair & 0xffffu) : last * 0x01010101u;
-        if (n >= 48u) {
-            /* long run: bytes up to a 16-byte boundary, then whole 16-byte stores; the rest below */
-            uint32_t head = (16u - (uint32_t)(((uintptr_t)p + fill) & 15u)) & 15u;
-            n -= head;
-            while (head) {
-                const uint32_t take = head < 4u ? head : 4u;
-                acc |= (unsigned long long)(pat & (take == 4u ? 0xffffffffu : ((1u << (8u * take)) - 1u))) << (8u * fill);
-                fill += take; head -= take;
-                if (fill >= 4u) { pk_store4(p, (uint32_t)acc); p += 4; acc >>= 32; fill -= 4u; }
+            if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) {
+                if (n == 1u) last = (e >> TOK_SYM_SHIFT) & 0xffu;
+                buf >>= t; nb -= (int)t; pos += t;
+            } else {
+                const uint32_t g = walk_general_token(sh, pos);
+                if (g == 0u) break;
+                t = g & 0xffu; n = (g >> 8) & 0x1ffu;
+                if (g & WG_LIT) last = (g >> 18) & 0xffu;
+                pos += t;
+                wi = pos >> 5;
+                buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
+                nb = 64 - (int)(pos & 31u);
+                wi += 2;
             }
-            for (uint32_t j = 0; j < fill; j++) p[j] = (uint8_t)(acc >> (8u * j));
-            p += fill; acc = 0; fill = 0;
+            pat = last * 0x01010101u;
+            if (DBL && pair) { const uint32_t b1 = (e >> 9) & 0xffu; pat = ((e >> TOK_SYM_SHIFT) & 0xffu) | (b1 << 8); last = b1; }
+            rem = n;
+        }
+        if (rem >= 16u && fill == 0u) { /* (a run of 8 or more bytes leaves fill == 0 behind its first iteration) */
             const uint4 v = make_uint4(pat, pat, pat, pat);
-            for (; n >= 16u; n -= 16u) { *reinterpret_cast<uint4 *>(p) = v; p += 16; }
+            __builtin_memcpy(p, &v, 16);
+            p += 16; rem -= 16u;
+            continue;
         }
-        while (n) {
-            const uint32_t take = n < 4u ? n : 4u;
-            acc |= (unsigned long long)(pat & (take == 4u ? 0xffffffffu : ((1u << (8u * take)) - 1u))) << (8u * fill);
-            fill += take; n -= take;
-            if (fill >= 4u) { pk_store4(p, (uint32_t)acc); p += 4; acc >>= 32; fill -= 4u; }
-        }
+        const uint32_t room = 8u - fill;
+        const uint32_t take = rem < room ? rem : room;   /* 1..8 */
+        const unsigned long long pat64 = ((unsigned long long)pat << 32) | pat;
+        const unsigned long long m = take >= 8u ? ~0ull : ((1ull << (8u * take)) - 1ull);
+        acc |= (pat64 & m) << (8u * fill);
+        fill += take; rem -= take;
+        if (fill >= 4u) { pk_store4(p, (uint32_t)acc); p += 4; acc >>= 32; fill -= 4u; }
+        if (fill >= 4u) { pk_store4(p, (uint32_t)acc); p += 4; acc >>= 32; fill -= 4u; }
     }
     for (uint32_t j = 0; j < fill; j++) p[j] = (uint8_t)(acc >> (8u * j));
 }
@@ -1110,8 +1408,25 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         /* P3: walk from the true entry, counting */
         SubResult r;
         const bool dbl = sh.dbl != 0u; /* (block-uniform) */
-        if (start != POS_INVALID) r = dbl ? count_walk<true, false, true>(sh, start, limit) : count_walk<true>(sh, start, limit);
-        else { r.land = POS_INVALID; r.nout = 0; r.flags = 0; r.lastlit = 0; } /* behind END_BLOCK or behind a token the walk of an earlier lane flags */
+#ifndef MRCZ_LEAN_COUNT
+#define MRCZ_LEAN_COUNT 0
+#endif
+#ifndef MRCZ_STAGED
+#define MRCZ_STAGED 1
+#endif
+        /* blocks of long codes keep the bytes their count walk decodes (stage_walk) */
+        const bool staged = MRCZ_STAGED && !dbl && sub <= 37u * sh.mintok; /* (block- and window-uniform) */
+        Staged sg;
+        sg.cnt = STG_SLOW; sg.w9 = 0;
+        if (staged) {
+            if (start != POS_INVALID) r = stage_walk(sh, start, limit, tid, sg);
+            else { r.land = POS_INVALID; r.nout = 0; r.flags = 0; r.lastlit = 0; }
+        } else if (MRCZ_LEAN_COUNT) {
+            const uint32_t s0 = start != POS_INVALID ? start : 0u, l0 = start != POS_INVALID ? limit : 0u;
+            r = dbl ? count_walk_lean<true, true>(sh, s0, l0) : count_walk_lean<true, false>(sh, s0, l0);
+            if (start == POS_INVALID) r.land = POS_INVALID; /* behind END_BLOCK or behind a token the walk of an earlier lane flags */
+        } else if (start != POS_INVALID) r = dbl ? count_walk<true, false, true>(sh, start, limit) : count_walk<true>(sh, start, limit);
+        else { r.land = POS_INVALID; r.nout = 0; r.flags = 0; r.lastlit = 0; }
         PHASE(4);
         const bool active = start != POS_INVALID;
         const uint32_t haslit0 = sh.haslit; /* (thread PT-1 rewrites them at the end of the window) */
@@ -1168,8 +1483,13 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
                 if ((uint32_t)tid == ws.firstlit_tid) sh.lead = op + myoff + (dbl ? count_walk<false, true, true>(sh, start, limit).nout : count_walk<false, true>(sh, start, limit).nout);
             }
         } else wout = sv.out + op + myoff;
+#ifndef EXP_SKIP_P4
+#define EXP_SKIP_P4 0
+#endif
+        if (EXP_SKIP_P4 == 1 || (EXP_SKIP_P4 == 2 && sh.mintok >= 7u) || (EXP_SKIP_P4 == 3 && sh.mintok < 7u)) wout = nullptr; /* what-if timing builds only */
         if (active && r.nout && wout) {
-            if (dbl) write_walk<true>(sh, start, limit, wout, before ? (before & 0xffu) : lastin);
+            if (staged && !(sg.cnt & STG_SLOW)) staged_copy_out(sh, tid, sg, wout);
+            else if (dbl) write_walk<true>(sh, start, limit, wout, before ? (before & 0xffu) : lastin);
             else write_walk<false>(sh, start, limit, wout, before ? (before & 0xffu) : lastin);
         }
         PHASE(6);
