@@ -79,16 +79,21 @@ struct HuffDecD : HuffAuxT<32> {
 /* The literal/length code has no table of its own: its fast entries share the dwords of ParShared::tok with the
  * token tables, so that a walk step is ONE LDS read.  tok[idx], idx = next LBITS stream bits:
  *   bits  0..7   total bits of the token when idx determines them (1..MAXTOK), X_EOB, X_ERR; 0 = general path
- *   bits  8..16  plane bytes the token produces (1 literal, 3..258 match), TOK_NOTD1 = match with distance != 1
- *   bits 17..25  literal/length symbol, bits 26..29 its code length (0 = code longer than LBITS)
+ *   bits  8..16  literal/length symbol (a literal's byte is byte 1 of the entry), bits 26..29 its code length (0 = code longer than LBITS)
+ *   bits 17..25  plane bytes the token produces (1 literal, 3..258 match), TOK_NOTD1 = match with distance != 1
  * A LITERAL whose successor is a literal too, both codes inside the LBITS index bits, may carry the second one as well
  * (blocks of short codes: the exponent plane, a mantissa plane masked down to a few bits): bit 30 marks such an entry,
- * bits 9..16 = the second byte, and bits 26..29 hold the SECOND code's length (the first one's is the token's bits).  Byte 0
+ * bits 18..25 = the second byte, and bits 26..29 hold the SECOND code's length (the first one's is the token's bits).  Byte 0
  * stays the FIRST token's bits, so the exit functions (which must see every token start) read the table as before; the two
  * walks take both literals in one step when the second one starts inside their piece. */
 constexpr uint32_t TOK_NOTD1 = 0x1ffu;
-constexpr int TOK_SYM_SHIFT = 17, TOK_LEN_SHIFT = 26;
+constexpr int TOK_SYM_SHIFT = 8, TOK_N_SHIFT = 17, TOK_B2_SHIFT = 18, TOK_LEN_SHIFT = 26;
 constexpr uint32_t TOK_PAIR = 1u << 30;
+/* bit 31: the entry does not give the walks everything (token bits 0 = "ask token_bits()", X_STOP, a match at another distance):
+ * ONE sign test sends a walk to its slow path.  (The kernel is bound by the number of vector instructions it issues -- running
+ * P1 twice, or adding two dozen comparisons per group to it, lengthens it in proportion -- so the walks' steps are kept as short
+ * as the format allows.) */
+constexpr uint32_t TOK_SLOW = 1u << 31;
 __device__ __forceinline__ uint32_t tok_second_len(uint32_t e) { return (e & TOK_PAIR) ? (e >> TOK_LEN_SHIFT) & 15u : 0u; }
 
 
@@ -147,11 +152,11 @@ __device__ __forceinline__ uint32_t lb_get(LdsBits &b, int n)
     return v;
 }
 
-/* All PT threads (uniform control flow): canonical-code tables for `n` <= 320 code lengths.
- * Symbol t is owned by thread t; ranks among equal lengths come from wave ballots.  `lut` may be
- * h.lut (LBITS index bits) or a smaller table with `lutbits` index bits. */
-template <int SYMSHIFT, int LENSHIFT, class H, class LutT>
-__device__ __forceinline__ void huff_build(H &h, const uint8_t *lens, int n, int tid, LutT *lut, int lutbits)
+/* All PT threads (uniform control flow): canonical-code bookkeeping for `n` <= 320 code lengths: counts, first codes, limits,
+ * symbols sorted by (length, value).  Symbol t is owned by thread t; ranks among equal lengths come from wave ballots.
+ * Returns the canonical code of the thread's symbol (meaningless if its length is 0).  Ends with a barrier. */
+template <class H>
+__device__ __forceinline__ uint32_t huff_core(H &h, const uint8_t *lens, int n, int tid)
 {
     const int w = tid >> 6, l = tid & 63;
     const int mylen = tid < n ? lens[tid] : 0;
@@ -182,16 +187,25 @@ __device__ __forceinline__ void huff_build(H &h, const uint8_t *lens, int n, int
         }
     }
     __syncthreads();
+    uint32_t code = 0;
     if (mylen) {
         uint32_t base = 0;
         for (int ww = 0; ww < w; ww++) base += h.wcnt[ww][mylen];
         const uint32_t r = base + (uint32_t)rank;
         h.sorted[h.offs[mylen] + r] = (uint16_t)tid;
+        code = (uint32_t)h.first[mylen] + r;
     }
     __syncthreads();
-    /* fast table, filled entry by entry (a short code covers thousands of entries: never let one
-     * thread loop over them): the entry's bit-reversed index, compared against the per-length
-     * limits, gives the code length; every entry is written, so no zeroing pass is needed */
+    return code;
+}
+/* ... and the fast table of a code, `lutbits` index bits (`lut` may be h.lut or a smaller table): filled entry by entry (a short
+ * code covers thousands of entries: never let one thread loop over them): the entry's bit-reversed index, compared against the
+ * per-length limits, gives the code length; every entry is written, so no zeroing pass is needed.  (The literal/length code's
+ * 4096-entry table is filled the other way round, symbol by symbol: tok_table_build.) */
+template <int SYMSHIFT, int LENSHIFT, class H, class LutT>
+__device__ __forceinline__ void huff_build(H &h, const uint8_t *lens, int n, int tid, LutT *lut, int lutbits)
+{
+    (void)huff_core(h, lens, n, tid);
     for (uint32_t idx = (uint32_t)tid; idx < (1u << lutbits); idx += PT) {
         const uint32_t x = (__brev(idx) >> (32 - lutbits)) << (15 - lutbits); /* left-justified 15-bit prefix */
         int len = 0;
@@ -274,31 +288,75 @@ __device__ __noinline__ uint32_t token_bits(const ParShared &sh, unsigned long l
     return t > (uint32_t)MAXTOK ? X_ERR : t;
 }
 
-/* entry of the fast token table for the 10-bit pattern idx: the token's total bits when they are
- * fully determined by those 10 bits (literal / END_BLOCK code <= 10 bits, or a match whose length
- * code + extra bits + distance CODE fit in 10 bits), else 0 = ask token_bits() */
-__device__ __forceinline__ uint32_t fast_token_entry(const ParShared &sh, uint32_t idx, uint32_t *nbytes)
+/* entry of the token table for the LBITS-bit pattern idx, which starts with the code (l bits) of literal/length symbol sym: the
+ * token's total bits when the pattern determines them (a literal or END_BLOCK, or a match whose extra bits and distance CODE
+ * fit in what is left of the pattern), else token bits 0 = "ask token_bits()"; TOK_SLOW on everything the walks do not take in
+ * one step. */
+__device__ __forceinline__ uint32_t tok_entry(const ParShared &sh, uint32_t sym, uint32_t l, uint32_t idx)
 {
-    *nbytes = 0;
-    const uint32_t e = sh.tok[idx];
-    if (!(e >> TOK_LEN_SHIFT)) return 0;
-    const uint32_t l = e >> TOK_LEN_SHIFT, sym = (e >> TOK_SYM_SHIFT) & 511u;
-    if (sym < 256u) { *nbytes = 1; return l; }
-    if (sym == 256u) return X_EOB;
+    const uint32_t base = (sym << TOK_SYM_SHIFT) | (l << TOK_LEN_SHIFT);
+    if (sym < 256u) return base | l | (1u << TOK_N_SHIFT);
+    if (sym == 256u) return base | X_EOB | TOK_SLOW;
     const int lc = (int)sym - 257;
-    if (lc >= 29) return X_ERR;
+    if (lc >= 29) return base | X_ERR | TOK_SLOW;
     const uint32_t xb = (uint32_t)len_extra_bits(lc);
-    if (l + xb >= (uint32_t)LBITS) return 0;
+    if (l + xb >= (uint32_t)LBITS) return base | TOK_SLOW;
     const uint32_t avail = (uint32_t)LBITS - l - xb;
     const uint32_t de = sh.dist.lut[(idx >> (l + xb)) & ((1u << DBITS) - 1u)];
-    if (!de) return 0;
+    if (!de) return base | TOK_SLOW;
     const uint32_t dc = de & 511u, dl = de >> 9;
-    if (dl > avail) return 0;
-    if (dc >= 30u) return X_ERR;
+    if (dl > avail) return base | TOK_SLOW;
+    if (dc >= 30u) return base | X_ERR | TOK_SLOW;
     const uint32_t dxb = dc < 4u ? 0u : (dc >> 1) - 1u;
     const uint32_t t = l + xb + dl + dxb;
-    *nbytes = dc == 0u ? base_len_of(lc) + ((idx >> l) & ((1u << xb) - 1u)) : TOK_NOTD1;
-    return t > (uint32_t)MAXTOK ? X_ERR : t;
+    if (t > (uint32_t)MAXTOK) return base | X_ERR | TOK_SLOW;
+    if (dc != 0u) return base | t | (TOK_NOTD1 << TOK_N_SHIFT) | TOK_SLOW;
+    return base | t | ((base_len_of(lc) + ((idx >> l) & ((1u << xb) - 1u))) << TOK_N_SHIFT);
+}
+/* The literal/length code's token table, symbol by symbol: a symbol whose code has l <= LBITS bits owns the 2^(LBITS - l) patterns
+ * that start with it.  Symbols of 7 bits and more (at most 32 patterns each) are filled by their own thread; the few shorter ones
+ * (a thousand patterns and more) by the whole workgroup, one after the other; patterns no code of <= LBITS bits starts are left
+ * at "ask" (TOK_SLOW, token bits 0).  An entry costs an address and a store -- the table used to be filled pattern by
+ * pattern, each pattern searching its code length among the limits and then recomputed once more for the token fields:
+ * a fifth of the kernel's vector instructions.  `mycode` = huff_core's canonical code of the thread's symbol.  sh.complete says
+ * whether every pattern got its token bits. */
+__device__ __forceinline__ void tok_table_build(ParShared &sh, int tid, uint32_t mycode)
+{
+    constexpr int EPT = (1 << LBITS) / PT;
+#pragma unroll
+    for (int k = 0; k < EPT; k++) sh.tok[tid + k * PT] = TOK_SLOW;
+    if (tid == 0) {
+        uint32_t cov = 0; /* patterns owned by the codes of <= LBITS bits */
+        for (int len = 1; len <= LBITS; len++) cov += (uint32_t)sh.lit.count[len] << (LBITS - len);
+        sh.complete = cov == (1u << LBITS) ? 1u : 0u;
+    }
+    __syncthreads();
+    bool zero = false;
+    const uint32_t mylen = (uint32_t)tid < sh.nlen ? sh.lens[tid] : 0u;
+    if (mylen >= 7u && mylen <= (uint32_t)LBITS) {
+        const uint32_t rev = __brev(mycode) >> (32u - mylen);
+        for (uint32_t h = 0; h < (1u << ((uint32_t)LBITS - mylen)); h++) {
+            const uint32_t idx = (rev | (h << mylen)) & ((1u << LBITS) - 1u);
+            const uint32_t e = tok_entry(sh, (uint32_t)tid, mylen, idx);
+            zero |= (e & 0xffu) == 0u;
+            sh.tok[idx] = e;
+        }
+    }
+    const uint32_t nshort = sh.lit.offs[7]; /* symbols with codes of 1..6 bits: the first ones of the sorted list */
+    for (uint32_t i = 0; i < nshort; i++) { /* (workgroup-uniform) */
+        const uint32_t sym = sh.lit.sorted[i], l = sh.lens[sym] & 7u;
+        if (l == 0u) continue; /* (never: the sorted list holds coded symbols) */
+        const uint32_t code = (uint32_t)sh.lit.first[l] + (i - (uint32_t)sh.lit.offs[l]);
+        const uint32_t rev = __brev(code) >> (32u - l);
+        for (uint32_t h = (uint32_t)tid; h < (1u << ((uint32_t)LBITS - l)); h += PT) {
+            const uint32_t idx = (rev | (h << l)) & ((1u << LBITS) - 1u);
+            const uint32_t e = tok_entry(sh, sym, l, idx);
+            zero |= (e & 0xffu) == 0u;
+            sh.tok[idx] = e;
+        }
+    }
+    if (zero) sh.complete = 0;
+    __syncthreads();
 }
 
 /* P1: exit values of the piece that starts at dword 8 * piece of the staged window, by a backward recurrence kept in
@@ -378,98 +436,11 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
         sh.ring[q][tid] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (ex[3] << 24); /* positions kbase + 4q .. + 3 */
     }
 }
-#ifndef MRCZ_P1_PIPE
-#define MRCZ_P1_PIPE 1
-#endif
-/* The same recurrence, software-pipelined.  A group of four positions needs two LDS round trips -- the token bits of its four
- * positions (table), then the exits those land on (ring) -- and only the second one depends on the groups before it.  So the
- * table bytes of group g - 1 are requested before the ring reads of group g are issued: one round trip per group instead of
- * two on the lane's critical path (the compiler cannot do that itself: it must assume the ring stores alias the table).  The
- * window dwords of the next word are fetched a whole word ahead for the same reason. */
-__device__ __forceinline__ unsigned long long piece_word_bits(const ParShared &sh, uint32_t tid, int wq, uint32_t lead, uint32_t nw)
-{
-    const uint32_t wi0 = tid * nw + (uint32_t)wq;
-    const uint32_t wp0 = sh.win[WSK(wi0)], wp1 = sh.win[WSK(wi0 + 1u)], wp2 = sh.win[WSK(wi0 + 2u)];
-    const unsigned long long a01 = ((unsigned long long)wp1 << 32) | wp0, a12 = ((unsigned long long)wp2 << 32) | wp1;
-    return ((a12 >> lead) << 32) | (uint32_t)(a01 >> lead);
-}
-/* byte offset into ParShared::tok of the entry for the LBITS stream bits at position sft (0..31) of the funnelled word */
-__device__ __forceinline__ uint32_t tok_byte_off(unsigned long long w01, int sft)
-{
-    return sft >= 2 ? (uint32_t)(w01 >> (sft - 2)) & (((1u << LBITS) - 1u) << 2) : (uint32_t)((w01 << 2) >> sft) & (((1u << LBITS) - 1u) << 2);
-}
-template <bool TAIL, bool MIN4, bool COMPLETE>
-__device__ __forceinline__ void piece_exit_word_pipe(ParShared &sh, uint32_t tid, int wq, uint32_t nw, unsigned long long w01,
-                                                     unsigned long long wnext /* the word below (wq - 1), valid when wq > 0 */, uint32_t tt[4] /* in: table bytes of this word's group 7; out: of the next word's */)
-{
-    const uint8_t *tokb = reinterpret_cast<const uint8_t *>(sh.tok);
-    const uint8_t *ringb = reinterpret_cast<const uint8_t *>(&sh.ring[0][0]);
-    const uint32_t lane4 = tid << 2;
-#pragma unroll
-    for (int q = 7; q >= 0; q--) {
-        uint32_t tn[4] = {0, 0, 0, 0};
-        if (q > 0) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) tn[j] = tokb[tok_byte_off(w01, 4 * (q - 1) + j)];
-        } else if (wq > 0) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) tn[j] = tokb[tok_byte_off(wnext, 28 + j)];
-        }
-        if (!TAIL) sh.ring[(q + 7) & 7][tid] = X_STOP * 0x01010101u; /* (see piece_exit_word) */
-        if (!COMPLETE) {
-            if ((tt[0] == 0u) | (tt[1] == 0u) | (tt[2] == 0u) | (tt[3] == 0u)) {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (tt[j] == 0u) tt[j] = token_bits(sh, w01 >> (4 * q + j));
-            }
-        }
-        uint32_t ex[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            /* ring_off(position + token bits); the word's base (a multiple of 32) falls outside the mask */
-            const uint32_t c = (uint32_t)(4 * q + j) * 0x201u;
-            ex[j] = ringb[((tt[j] * 0x201u + c) & 0x3803u) | lane4];
-        }
-        if (TAIL) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t x = 32u * (uint32_t)wq + (uint32_t)(4 * q + j) + tt[j];
-                ex[j] = tt[j] >= X_STOP ? X_STOP : (x >= 32u * nw ? x - 32u * nw : ex[j]);
-            }
-        }
-        if (!MIN4) {
-            if (tt[2] == 1u) ex[2] = ex[3];
-            if (tt[1] == 1u) ex[1] = ex[2];
-            if (tt[1] == 2u) ex[1] = ex[3];
-            if (tt[0] == 1u) ex[0] = ex[1];
-            if (tt[0] == 2u) ex[0] = ex[2];
-            if (tt[0] == 3u) ex[0] = ex[3];
-        }
-        sh.ring[q][tid] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (ex[3] << 24);
-#pragma unroll
-        for (int j = 0; j < 4; j++) tt[j] = tn[j];
-    }
-}
 template <bool MIN4, bool COMPLETE>
 __device__ __forceinline__ void piece_exit_lds(ParShared &sh, uint32_t tid, uint32_t lead, uint32_t nw)
 {
-#if MRCZ_P1_PIPE
-    const uint8_t *tokb = reinterpret_cast<const uint8_t *>(sh.tok);
-    unsigned long long w = piece_word_bits(sh, tid, (int)nw - 1, lead, nw);
-    unsigned long long wn = nw > 1u ? piece_word_bits(sh, tid, (int)nw - 2, lead, nw) : 0ull;
-    uint32_t tt[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) tt[j] = tokb[tok_byte_off(w, 28 + j)];
-    piece_exit_word_pipe<true, MIN4, COMPLETE>(sh, tid, (int)nw - 1, nw, w, wn, tt);
-    for (int wq = (int)nw - 2; wq >= 0; wq--) {
-        w = wn;
-        wn = wq > 0 ? piece_word_bits(sh, tid, wq - 1, lead, nw) : 0ull;
-        piece_exit_word_pipe<false, MIN4, COMPLETE>(sh, tid, wq, nw, w, wn, tt);
-    }
-#else
     piece_exit_word<true, MIN4, COMPLETE>(sh, tid, (int)nw - 1, lead, nw);
     for (int wq = (int)nw - 2; wq >= 0; wq--) piece_exit_word<false, MIN4, COMPLETE>(sh, tid, wq, lead, nw);
-#endif
 }
 
 
@@ -490,181 +461,97 @@ struct SubResult {
     uint32_t lastlit; /* 0x100 | byte if the lane decoded a literal, else 0 */
 };
 
+constexpr uint32_t WG_LIT = 1u << 17; /* walk_general_token / count_general_token: the token is a literal, byte << 18 */
+/* A token the table marks TOK_SLOW (code longer than the index, END_BLOCK, a match whose fields do not fit, another distance),
+ * at window bit `pos`, for the counting walks: bits | bytes << 8 | (literal: WG_LIT | byte << 18) | CG_STOP when the lane's walk ends
+ * here (then bits = those of END_BLOCK, so that the position is just past it) | F_EOB / F_ERR / F_GENERAL << CG_FLAG_SHIFT.  Rare,
+ * so out of line: the walk loops stay small. */
+constexpr uint32_t CG_STOP = 1u << 31;
+constexpr int CG_FLAG_SHIFT = 26; /* F_EOB / F_ERR / F_GENERAL of the token (returned in the value: a pointer argument would pin the caller's counters in scratch memory) */
+__device__ __noinline__ uint32_t count_general_token(const ParShared &sh, uint32_t pos)
+{
+    auto peek = [&](uint32_t p) -> uint32_t { /* >= 32 bits from window bit p */
+        const uint32_t i = p >> 5;
+        return (uint32_t)((((unsigned long long)sh.win[WSK(i + 1u)] << 32) | sh.win[WSK(i)]) >> (p & 31u));
+    };
+    constexpr uint32_t ERR = CG_STOP | ((uint32_t)F_ERR << CG_FLAG_SHIFT);
+    const uint32_t d = huff_decode_lit(sh, peek(pos));
+    if (d == 0xffffffffu) return ERR;
+    const uint32_t l = d >> 16, sym = d & 0xffffu;
+    if (sym < 256u) return l | (1u << 8) | WG_LIT | (sym << 18);
+    if (sym == 256u) return l | CG_STOP | ((uint32_t)F_EOB << CG_FLAG_SHIFT);
+    const int lc = (int)sym - 257;
+    if (lc >= 29) return ERR;
+    const uint32_t xb = (uint32_t)len_extra_bits(lc);
+    const uint32_t ml = base_len_of(lc) + (peek(pos + l) & ((1u << xb) - 1u));
+    const uint32_t dbits = peek(pos + l + xb);
+    /* what the exit functions (token_bits) call unresolvable must be flagged by the lane that walks into it: the pieces behind
+     * it only know that the chain stopped */
+    if (!sh.dist.lut[dbits & ((1u << DBITS) - 1u)]) return ERR; /* distance code beyond the fast table */
+    const uint32_t dd = huff_decode_dist(sh.dist, dbits);
+    if (dd == 0xffffffffu || (dd & 0xffffu) >= 30u) return ERR;
+    const uint32_t dl = dd >> 16, dc = dd & 0xffffu;
+    const uint32_t dxb = dc < 4u ? 0u : (dc >> 1) - 1u;
+    if (l + xb + dl + dxb > (uint32_t)MAXTOK) return ERR; /* longer than the exit functions follow */
+    const uint32_t dist = base_dist_of((int)dc) + (peek(pos + l + xb + dl) & ((1u << dxb) - 1u));
+    return (l + xb + dl + dxb) | (ml << 8) | (dist != 1u ? (uint32_t)F_GENERAL << CG_FLAG_SHIFT : 0u);
+}
+
+/* the walks' bit buffer: 64 bits of the window from bit `pos` on */
+#define WALK_BITS_INIT(pos_)                                                                                          \
+    uint32_t wi = (pos_) >> 5;                                                                                        \
+    uint64_t buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> ((pos_) & 31u);            \
+    int nb = 64 - (int)((pos_) & 31u);                                                                                \
+    wi += 2
+#define WALK_BITS_RESYNC(pos_)                                                                                        \
+    do {                                                                                                              \
+        wi = (pos_) >> 5;                                                                                             \
+        buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> ((pos_) & 31u);                 \
+        nb = 64 - (int)((pos_) & 31u);                                                                                \
+        wi += 2;                                                                                                      \
+    } while (0)
+
 /* P3: count walk.  Decode tokens from window bit `start` until the position reaches `limit` (or
- * END_BLOCK), counting the plane bytes they produce.  Nearly every token is sized by the two fast
- * tables (token bits, produced bytes) with a single 12-bit lookup each. */
+ * END_BLOCK), counting the plane bytes they produce.  Nearly every token is sized by ONE 12-bit lookup. */
 template <bool TRACK_LAST, bool STOP_AT_LIT = false, bool DBL = false, bool NLIT = false /* count literal tokens instead of bytes */>
 __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t start, uint32_t limit)
 {
     SubResult r;
     r.nout = 0; r.flags = 0; r.lastlit = 0;
     uint32_t pos = start;
-    uint32_t wi = pos >> 5;
-    uint64_t buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
-    int nb = 64 - (int)(pos & 31u);
-    wi += 2;
+    uint32_t laste = 0; /* table entry of the last literal decoded (its byte is taken out once, behind the loop) */
+    WALK_BITS_INIT(pos);
     while (pos < limit) {
         if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
-        const uint32_t idx = (uint32_t)buf & ((1u << LBITS) - 1u);
-        const uint32_t e = sh.tok[idx];
-        const uint32_t t = e & 0xffu;
-        uint32_t n = (e >> 8) & 0x1ffu;
-        if (DBL) {
-            const uint32_t l2 = tok_second_len(e);
-            if (l2) {
+        const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
+        if ((int32_t)e >= 0) { /* 1 <= token bits <= MAXTOK, distance 1 */
+            const uint32_t t = e & 0xffu;
+            if (DBL && (e & TOK_PAIR)) { /* two literals */
                 if (STOP_AT_LIT) break;
-                n = 1u;
-                if (pos + t < limit) { /* the second literal starts inside this piece: both in one step */
-                    buf >>= t + l2; nb -= (int)(t + l2); pos += t + l2;
-                    r.nout += 2u;
-                    if (TRACK_LAST) r.lastlit = 0x100u | ((e >> 9) & 0xffu);
-                    continue;
-                }
+                const bool both = pos + t < limit; /* the second literal starts inside this piece: both in one step */
+                const uint32_t tt = t + (both ? (e >> TOK_LEN_SHIFT) & 15u : 0u);
+                buf >>= tt; nb -= (int)tt; pos += tt;
+                r.nout += both ? 2u : 1u;
+                if (TRACK_LAST) { r.lastlit = 0x100u | (both ? (e >> TOK_B2_SHIFT) & 0xffu : (e >> TOK_SYM_SHIFT) & 0xffu); laste = 0; }
+                continue;
             }
-        }
-        if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) { /* 1 <= t <= MAXTOK, distance 1 */
+            const uint32_t n = (e >> TOK_N_SHIFT) & 0x1ffu;
             if (STOP_AT_LIT && n == 1u) break;
             buf >>= t; nb -= (int)t; pos += t;
             r.nout += NLIT ? (n == 1u ? 1u : 0u) : n;
-            if (TRACK_LAST && n == 1u) r.lastlit = 0x100u | ((e >> TOK_SYM_SHIFT) & 0xffu);
+            if (TRACK_LAST) laste = n == 1u ? e : laste;
             continue;
         }
-        /* general path: long codes, END_BLOCK, other distances, errors */
-        const uint32_t d = huff_decode_lit(sh, (uint32_t)buf);
-        if (d == 0xffffffffu) { r.flags |= F_ERR; break; }
-        const int l = (int)(d >> 16);
-        const uint32_t sym = d & 0xffffu;
-        if (STOP_AT_LIT && sym < 256u) break;
-        buf >>= l; nb -= l; pos += (uint32_t)l;
-        if (sym < 256u) {
-            r.nout++;
-            if (TRACK_LAST) r.lastlit = 0x100u | sym;
-        } else if (sym == 256u) {
-            r.flags |= F_EOB;
-            break;
-        } else {
-            const int lc = (int)sym - 257;
-            if (lc >= 29) { r.flags |= F_ERR; break; }
-            const int xb = len_extra_bits(lc);
-            const uint32_t ml = base_len_of(lc) + ((uint32_t)buf & ((1u << xb) - 1u));
-            buf >>= xb; nb -= xb; pos += (uint32_t)xb;
-            if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
-            /* what the exit functions (token_bits) call unresolvable must be flagged by the lane that walks into it: the pieces
-             * behind it only know that the chain stopped */
-            if (!sh.dist.lut[(uint32_t)buf & ((1u << DBITS) - 1u)]) { r.flags |= F_ERR; break; } /* distance code beyond the fast table */
-            const uint32_t dd = huff_decode_dist(sh.dist, (uint32_t)buf);
-            if (dd == 0xffffffffu || (dd & 0xffffu) >= 30u) { r.flags |= F_ERR; break; }
-            const int dl = (int)(dd >> 16), dc = (int)(dd & 0xffffu);
-            buf >>= dl; nb -= dl; pos += (uint32_t)dl;
-            const int dxb = dc < 4 ? 0 : (dc >> 1) - 1;
-            if (l + xb + dl + dxb > MAXTOK) { r.flags |= F_ERR; break; }                          /* longer than the exit functions follow */
-            const uint32_t dist = base_dist_of(dc) + ((uint32_t)buf & ((1u << dxb) - 1u));
-            buf >>= dxb; nb -= dxb; pos += (uint32_t)dxb;
-            if (dist != 1u) r.flags |= F_GENERAL;
-            r.nout += NLIT ? 0u : ml;
-        }
+        const uint32_t g = count_general_token(sh, pos);
+        if (STOP_AT_LIT && (g & WG_LIT)) break;
+        r.flags |= (g >> CG_FLAG_SHIFT) & 7u;
+        pos += g & 0xffu;
+        if (g & CG_STOP) break;
+        r.nout += NLIT ? ((g & WG_LIT) ? 1u : 0u) : (g >> 8) & 0x1ffu;
+        if (TRACK_LAST && (g & WG_LIT)) { r.lastlit = 0x100u | ((g >> 18) & 0xffu); laste = 0; }
+        WALK_BITS_RESYNC(pos);
     }
-    r.land = pos;
-    return r;
-}
-
-constexpr uint32_t WG_LIT = 1u << 17; /* walk_general_token / count_general_token: the token is a literal, byte << 18 */
-/* ---- branch-lean walks ------------------------------------------------------------------------------------------------
- * The walks above are written as a lane would run them alone: a loop with a handful of nested ifs.  A wave turns every one of
- * those ifs into an exec-mask region (s_and_saveexec, a branch, s_or exec), ten or more per token, and the kernel's counters
- * showed it: one scalar and 0.15 branch instructions for every two vector ones, the walks two to five times longer than their
- * arithmetic.  The lean forms keep ALL lanes in one straight-line body per step -- a lane that has nothing to do advances by
- * zero bits -- with selects instead of ifs, one wave-uniform branch for the loop and one (rarely taken) for the tokens the
- * table does not resolve. */
-struct BitWin {       /* a lane's view of the staged window: dwords wi, wi + 1 (lo, hi) and wi + 2 (nxt) */
-    uint32_t lo, hi, nxt, wi, bo; /* bo = bit offset of the position inside lo (< 32) */
-};
-__device__ __forceinline__ void bw_init(BitWin &b, const ParShared &sh, uint32_t pos)
-{
-    b.wi = pos >> 5; b.bo = pos & 31u;
-    b.lo = sh.win[WSK(b.wi)]; b.hi = sh.win[WSK(b.wi + 1u)]; b.nxt = sh.win[WSK(b.wi + 2u)];
-}
-__device__ __forceinline__ uint32_t bw_peek(const BitWin &b) { return __builtin_amdgcn_alignbit(b.hi, b.lo, b.bo); } /* 32 bits from the position */
-__device__ __forceinline__ void bw_skip(BitWin &b, const ParShared &sh, uint32_t t /* < 32 */)
-{
-    b.bo += t;
-    const bool adv = b.bo >= 32u;
-    b.lo = adv ? b.hi : b.lo;
-    b.hi = adv ? b.nxt : b.hi;
-    b.wi += adv ? 1u : 0u;
-    b.bo -= adv ? 32u : 0u;
-    b.nxt = sh.win[WSK(b.wi + 2u)]; /* (every step, no test: its address does not wait for anything but wi) */
-}
-/* A token the table leaves to the slow path (code longer than the index, END_BLOCK, a match whose fields do not fit, other
- * distances), for the counting walks: bits | bytes << 8 | literal << 17 (WG_LIT | byte << 18) | CG_STOP when the lane's walk ends
- * here; *flags collects F_EOB / F_ERR / F_GENERAL exactly as count_walk() does. */
-constexpr uint32_t CG_STOP = 1u << 31;
-__device__ __noinline__ uint32_t count_general_token(const ParShared &sh, uint32_t pos, uint32_t *flags)
-{
-    auto peek = [&](uint32_t p) -> uint32_t {
-        const uint32_t i = p >> 5;
-        return (uint32_t)((((unsigned long long)sh.win[WSK(i + 1u)] << 32) | sh.win[WSK(i)]) >> (p & 31u));
-    };
-    const uint32_t d = huff_decode_lit(sh, peek(pos));
-    if (d == 0xffffffffu) { *flags |= F_ERR; return CG_STOP; }
-    const uint32_t l = d >> 16, sym = d & 0xffffu;
-    if (sym < 256u) return l | (1u << 8) | WG_LIT | (sym << 18);
-    if (sym == 256u) { *flags |= F_EOB; return l | CG_STOP; }
-    const int lc = (int)sym - 257;
-    if (lc >= 29) { *flags |= F_ERR; return CG_STOP; }
-    const uint32_t xb = (uint32_t)len_extra_bits(lc);
-    const uint32_t ml = base_len_of(lc) + (peek(pos + l) & ((1u << xb) - 1u));
-    const uint32_t dbits = peek(pos + l + xb);
-    if (!sh.dist.lut[dbits & ((1u << DBITS) - 1u)]) { *flags |= F_ERR; return CG_STOP; } /* distance code beyond the fast table */
-    const uint32_t dd = huff_decode_dist(sh.dist, dbits);
-    if (dd == 0xffffffffu || (dd & 0xffffu) >= 30u) { *flags |= F_ERR; return CG_STOP; }
-    const uint32_t dl = dd >> 16, dc = dd & 0xffffu;
-    const uint32_t dxb = dc < 4u ? 0u : (dc >> 1) - 1u;
-    if (l + xb + dl + dxb > (uint32_t)MAXTOK) { *flags |= F_ERR; return CG_STOP; }
-    const uint32_t dist = base_dist_of((int)dc) + (peek(pos + l + xb + dl) & ((1u << dxb) - 1u));
-    if (dist != 1u) *flags |= F_GENERAL;
-    return (l + xb + dl + dxb) | (ml << 8);
-}
-
-/* P3, lean: every lane of the wave calls it (a lane without a piece passes limit = 0); same results as count_walk<TRACK_LAST, false, DBL>. */
-template <bool TRACK_LAST, bool DBL>
-__device__ __forceinline__ SubResult count_walk_lean(const ParShared &sh, uint32_t start, uint32_t limit)
-{
-    SubResult r;
-    r.nout = 0; r.flags = 0; r.lastlit = 0;
-    uint32_t pos = start;
-    BitWin b;
-    bw_init(b, sh, pos);
-    while (__ballot(pos < limit) != 0ull) {
-        const bool act = pos < limit;
-        const uint32_t e = sh.tok[bw_peek(b) & ((1u << LBITS) - 1u)];
-        uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu, lit = (e >> TOK_SYM_SHIFT) & 0xffu;
-        bool islit = n == 1u;
-        if (DBL) {
-            const bool pair = (e & TOK_PAIR) != 0u;
-            const bool both = pair && pos + t < limit; /* the second literal starts inside this piece: both in one step */
-            n = pair ? (both ? 2u : 1u) : n;
-            lit = both ? (e >> 9) & 0xffu : lit;
-            t += both ? (e >> TOK_LEN_SHIFT) & 15u : 0u;
-            islit = islit || pair;
-        }
-        const bool fast = t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1;
-        bool go = act && fast;
-        if (__ballot(act && !fast) != 0ull) { /* rare */
-            if (act && !fast) {
-                const uint32_t g = count_general_token(sh, pos, &r.flags);
-                t = g & 0xffu; n = (g >> 8) & 0x1ffu; lit = (g >> 18) & 0xffu; islit = (g & WG_LIT) != 0u;
-                go = true;
-                if (g & CG_STOP) { n = 0u; islit = false; limit = 0u; } /* END_BLOCK: its bits still count (r.land is just past it) */
-                if (r.flags & F_ERR) t = 0u;
-            }
-        }
-        t = go ? t : 0u;
-        r.nout += go ? n : 0u;
-        if (TRACK_LAST) r.lastlit = (go && islit) ? (0x100u | lit) : r.lastlit;
-        pos += t;
-        bw_skip(b, sh, t);
-    }
+    if (TRACK_LAST && laste) r.lastlit = 0x100u | ((laste >> TOK_SYM_SHIFT) & 0xffu);
     r.land = pos;
     return r;
 }
@@ -682,62 +569,36 @@ __device__ __forceinline__ SubResult stage_walk(ParShared &sh, uint32_t start, u
     SubResult r;
     r.nout = 0; r.flags = 0; r.lastlit = 0;
     uint32_t pos = start;
-    uint32_t wi = pos >> 5;
-    uint64_t buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
-    int nb = 64 - (int)(pos & 31u);
-    wi += 2;
-    uint32_t cnt = 0, accw = 0, slow = 0;
+    uint32_t cnt = 0, accw = 0, slow = 0, laste = 0;
+    WALK_BITS_INIT(pos);
     while (pos < limit) {
         if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
         const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
-        const uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
-        if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) {
+        if ((int32_t)e >= 0) {
+            const uint32_t t = e & 0xffu, n = (e >> TOK_N_SHIFT) & 0x1ffu;
             buf >>= t; nb -= (int)t; pos += t;
             r.nout += n;
-            if (n == 1u) {
-                const uint32_t lit = (e >> TOK_SYM_SHIFT) & 0xffu;
-                r.lastlit = 0x100u | lit;
-                if (cnt < STG_CAP) {
-                    accw = (accw >> 8) | (lit << 24);
-                    cnt++;
-                    if ((cnt & 3u) == 0u && cnt <= 32u) sh.ring[(cnt >> 2) - 1u][tid] = accw;
-                } else slow = STG_SLOW;
-            } else slow = STG_SLOW;
+            if (n == 1u && cnt < STG_CAP) {
+                laste = e;
+                accw = __byte_perm(accw, e, 0x5321); /* accw >> 8 | literal << 24: the literal is byte 1 of its entry */
+                cnt++;
+                if ((cnt & 3u) == 0u && cnt <= 32u) sh.ring[(cnt >> 2) - 1u][tid] = accw;
+            } else {
+                if (n == 1u) laste = e;
+                slow = STG_SLOW;
+            }
             continue;
         }
-        /* general path: long codes, END_BLOCK, other distances, errors (as count_walk) */
         slow = STG_SLOW;
-        const uint32_t d = huff_decode_lit(sh, (uint32_t)buf);
-        if (d == 0xffffffffu) { r.flags |= F_ERR; break; }
-        const int l = (int)(d >> 16);
-        const uint32_t sym = d & 0xffffu;
-        buf >>= l; nb -= l; pos += (uint32_t)l;
-        if (sym < 256u) {
-            r.nout++;
-            r.lastlit = 0x100u | sym;
-        } else if (sym == 256u) {
-            r.flags |= F_EOB;
-            break;
-        } else {
-            const int lc = (int)sym - 257;
-            if (lc >= 29) { r.flags |= F_ERR; break; }
-            const int xb = len_extra_bits(lc);
-            const uint32_t ml = base_len_of(lc) + ((uint32_t)buf & ((1u << xb) - 1u));
-            buf >>= xb; nb -= xb; pos += (uint32_t)xb;
-            if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
-            if (!sh.dist.lut[(uint32_t)buf & ((1u << DBITS) - 1u)]) { r.flags |= F_ERR; break; }
-            const uint32_t dd = huff_decode_dist(sh.dist, (uint32_t)buf);
-            if (dd == 0xffffffffu || (dd & 0xffffu) >= 30u) { r.flags |= F_ERR; break; }
-            const int dl = (int)(dd >> 16), dc = (int)(dd & 0xffffu);
-            buf >>= dl; nb -= dl; pos += (uint32_t)dl;
-            const int dxb = dc < 4 ? 0 : (dc >> 1) - 1;
-            if (l + xb + dl + dxb > MAXTOK) { r.flags |= F_ERR; break; }
-            const uint32_t dist = base_dist_of(dc) + ((uint32_t)buf & ((1u << dxb) - 1u));
-            buf >>= dxb; nb -= dxb; pos += (uint32_t)dxb;
-            if (dist != 1u) r.flags |= F_GENERAL;
-            r.nout += ml;
-        }
+        const uint32_t g = count_general_token(sh, pos);
+        r.flags |= (g >> CG_FLAG_SHIFT) & 7u;
+        pos += g & 0xffu;
+        if (g & CG_STOP) break;
+        r.nout += (g >> 8) & 0x1ffu;
+        if (g & WG_LIT) { r.lastlit = 0x100u | ((g >> 18) & 0xffu); laste = 0; }
+        WALK_BITS_RESYNC(pos);
     }
+    if (laste) r.lastlit = 0x100u | ((laste >> TOK_SYM_SHIFT) & 0xffu);
     r.land = pos;
     sg.cnt = cnt | slow;
     sg.w9 = accw;
@@ -819,10 +680,7 @@ template <bool DBL>
 __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, uint32_t limit, uint8_t *out, uint32_t last)
 {
     uint32_t pos = start;
-    uint32_t wi = pos >> 5;
-    uint64_t buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
-    int nb = 64 - (int)(pos & 31u);
-    wi += 2;
+    WALK_BITS_INIT(pos);
     uint8_t *p = out;             /* where the low byte of acc goes */
     unsigned long long acc = 0;   /* pending bytes */
     uint32_t fill = 0;            /* bytes held in acc (< 4 at the top of the loop) */
@@ -833,31 +691,31 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
             if (pos >= limit) break;
             if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
             const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
-            uint32_t t = e & 0xffu, n = (e >> 8) & 0x1ffu;
-            bool pair = false;
-            if (DBL) {
-                const uint32_t l2 = tok_second_len(e);
-                if (l2) {
-                    n = 1u;
-                    if (pos + t < limit) { t += l2; n = 2u; pair = true; }
+            uint32_t n;
+            if ((int32_t)e >= 0) { /* 1 <= token bits <= MAXTOK, distance 1 */
+                uint32_t t = e & 0xffu;
+                n = (e >> TOK_N_SHIFT) & 0x1ffu;
+                if (DBL && (e & TOK_PAIR)) { /* two literals; both in one step when the second one starts inside this piece */
+                    const uint32_t b0 = (e >> TOK_SYM_SHIFT) & 0xffu, b1 = (e >> TOK_B2_SHIFT) & 0xffu;
+                    const bool both = pos + t < limit;
+                    t += both ? (e >> TOK_LEN_SHIFT) & 15u : 0u;
+                    n = both ? 2u : 1u;
+                    pat = both ? (b0 | (b1 << 8)) : b0 * 0x01010101u;
+                    last = both ? b1 : b0;
+                } else {
+                    last = n == 1u ? (e >> TOK_SYM_SHIFT) & 0xffu : last;
+                    pat = last * 0x01010101u;
                 }
-            }
-            if (t - 1u < (uint32_t)MAXTOK && n != TOK_NOTD1) {
-                if (n == 1u) last = (e >> TOK_SYM_SHIFT) & 0xffu;
                 buf >>= t; nb -= (int)t; pos += t;
             } else {
                 const uint32_t g = walk_general_token(sh, pos);
                 if (g == 0u) break;
-                t = g & 0xffu; n = (g >> 8) & 0x1ffu;
+                n = (g >> 8) & 0x1ffu;
                 if (g & WG_LIT) last = (g >> 18) & 0xffu;
-                pos += t;
-                wi = pos >> 5;
-                buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> (pos & 31u);
-                nb = 64 - (int)(pos & 31u);
-                wi += 2;
+                pat = last * 0x01010101u;
+                pos += g & 0xffu;
+                WALK_BITS_RESYNC(pos);
             }
-            pat = last * 0x01010101u;
-            if (DBL && pair) { const uint32_t b1 = (e >> 9) & 0xffu; pat = ((e >> TOK_SYM_SHIFT) & 0xffu) | (b1 << 8); last = b1; }
             rem = n;
         }
         if (rem >= 16u && fill == 0u) { /* (a run of 8 or more bytes leaves fill == 0 behind its first iteration) */
@@ -1272,47 +1130,50 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         return;
     }
     PHASE(14);
-    huff_build<TOK_SYM_SHIFT, TOK_LEN_SHIFT>(sh.lit, sh.lens, (int)sh.nlen, tid, sh.tok, LBITS);
+#ifndef EXP_DOUBLE
+#define EXP_DOUBLE 0
+#endif
+    const uint32_t mycode = huff_core(sh.lit, sh.lens, (int)sh.nlen, tid);
     PHASE(15);
     huff_build<0, 9>(sh.dist, sh.lens + sh.nlen, (int)sh.ndist, tid, sh.dist.lut, DBITS);
     PHASE(16);
-    if (tid == 0) sh.complete = 1; /* (the last barrier of huff_build is behind us; the ones below publish the verdict) */
-    bool anyzero = false;
+    if (EXP_DOUBLE & 4) tok_table_build(sh, tid, mycode); /* what-if timing builds only */
+    tok_table_build(sh, tid, mycode);
     {
-        /* every entry is computed from the symbol / code length fields huff_build left (read phase), then written */
+        /* Two literals per step: in blocks of short codes a literal's entry also carries the literal behind it when both codes fit
+         * in the index bits (no literal of 6 bits or less, no pairs: a mantissa plane skips the pass). */
         constexpr int EPT = (1 << LBITS) / PT;
-        uint32_t add[EPT], second[EPT];
-        uint32_t ndbl = 0;
+        bool pairs = false;
+        if (sh.lit.offs[7] != 0u) { /* (workgroup-uniform) */
+            uint32_t second[EPT];
+            uint32_t ndbl = 0;
 #pragma unroll
-        for (int k = 0; k < EPT; k++) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)(k * PT);
-            uint32_t nby;
-            const uint32_t t = fast_token_entry(sh, i, &nby);
-            add[k] = t | (nby << 8);
-            second[k] = 0;
-            anyzero |= t == 0u;
-            if (nby == 1u && t < (uint32_t)LBITS) { /* a literal: is the token behind it a literal inside the index bits too? */
-                const uint32_t e2 = sh.tok[i >> t];
-                const uint32_t l2 = e2 >> TOK_LEN_SHIFT, sym2 = (e2 >> TOK_SYM_SHIFT) & 511u;
-                if (l2 != 0u && t + l2 <= (uint32_t)LBITS && sym2 < 256u) { second[k] = TOK_PAIR | (l2 << TOK_LEN_SHIFT) | (sym2 << 9); ndbl++; }
+            for (int k = 0; k < EPT; k++) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)(k * PT);
+                const uint32_t e = sh.tok[i], t = e & 0xffu;
+                second[k] = 0;
+                if ((int32_t)e >= 0 && ((e >> TOK_N_SHIFT) & 0x1ffu) == 1u && t < (uint32_t)LBITS) { /* a literal: is the token behind it a literal inside the index bits too? */
+                    const uint32_t e2 = sh.tok[i >> t];
+                    const uint32_t l2 = (e2 >> TOK_LEN_SHIFT) & 15u, sym2 = (e2 >> TOK_SYM_SHIFT) & 511u;
+                    if (l2 != 0u && t + l2 <= (uint32_t)LBITS && sym2 < 256u) { second[k] = TOK_PAIR | (l2 << TOK_LEN_SHIFT) | (sym2 << TOK_B2_SHIFT); ndbl++; }
+                }
             }
-        }
-        if (ndbl) atomicAdd(&sh.dbl, ndbl);
-        __syncthreads();
-        /* worth the walks' extra test when a quarter of the patterns are pairs; otherwise the table stays as the plain walks read it */
-        const bool pairs = sh.dbl >= (1u << LBITS) / 4u;
+            if (ndbl) atomicAdd(&sh.dbl, ndbl);
+            __syncthreads();
+            /* worth the walks' extra test when a quarter of the patterns are pairs; otherwise the table stays as the plain walks read it */
+            pairs = sh.dbl >= (1u << LBITS) / 4u;
+            if (pairs) {
 #pragma unroll
-        for (int k = 0; k < EPT; k++) {
-            const uint32_t e = sh.tok[tid + k * PT] | add[k];
-            sh.tok[tid + k * PT] = (pairs && second[k]) ? ((e & ~(15u << TOK_LEN_SHIFT)) | second[k]) : e;
+                for (int k = 0; k < EPT; k++)
+                    if (second[k]) sh.tok[tid + k * PT] = (sh.tok[tid + k * PT] & ~(15u << TOK_LEN_SHIFT)) | second[k];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if (tid == 0) sh.dbl = pairs ? 1u : 0u;
     }
     /* longest token of this block: bounds the exit-function domain */
     if (tid == 0) { sh.dmax = 0; sh.maxtok = 1; sh.mintok = 15; }
     __syncthreads();
-    if (anyzero) sh.complete = 0;
     if ((uint32_t)tid < sh.ndist) {
         const uint32_t dl = sh.lens[sh.nlen + tid];
         if (dl) atomicMax(&sh.dmax, dl + ((uint32_t)tid < 4u ? 0u : ((uint32_t)tid >> 1) - 1u));
@@ -1349,6 +1210,10 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         uint32_t entry;
         {
             /* P1: exit values of my piece -> my column of sh.ring (rows 0..23 = exit function) */
+            if (EXP_DOUBLE & 1) { /* what-if timing builds only: P1 twice (idempotent) */
+                if (sh.mintok >= 4u) piece_exit_lds<true, false>(sh, (uint32_t)tid, wlead, nw);
+                else piece_exit_lds<false, false>(sh, (uint32_t)tid, wlead, nw);
+            }
             if (sh.complete) {
                 if (sh.mintok >= 4u) piece_exit_lds<true, true>(sh, (uint32_t)tid, wlead, nw);
                 else piece_exit_lds<false, true>(sh, (uint32_t)tid, wlead, nw);
@@ -1408,23 +1273,20 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         /* P3: walk from the true entry, counting */
         SubResult r;
         const bool dbl = sh.dbl != 0u; /* (block-uniform) */
-#ifndef MRCZ_LEAN_COUNT
-#define MRCZ_LEAN_COUNT 0
-#endif
 #ifndef MRCZ_STAGED
 #define MRCZ_STAGED 1
 #endif
         /* blocks of long codes keep the bytes their count walk decodes (stage_walk) */
         const bool staged = MRCZ_STAGED && !dbl && sub <= 37u * sh.mintok; /* (block- and window-uniform) */
+        if ((EXP_DOUBLE & 2) && start != POS_INVALID) { /* what-if timing builds only: one more count walk */
+            const SubResult x = dbl ? count_walk<true, false, true>(sh, start, limit) : count_walk<true>(sh, start, limit);
+            asm volatile("" :: "v"(x.nout), "v"(x.land), "v"(x.lastlit), "v"(x.flags));
+        }
         Staged sg;
         sg.cnt = STG_SLOW; sg.w9 = 0;
         if (staged) {
             if (start != POS_INVALID) r = stage_walk(sh, start, limit, tid, sg);
             else { r.land = POS_INVALID; r.nout = 0; r.flags = 0; r.lastlit = 0; }
-        } else if (MRCZ_LEAN_COUNT) {
-            const uint32_t s0 = start != POS_INVALID ? start : 0u, l0 = start != POS_INVALID ? limit : 0u;
-            r = dbl ? count_walk_lean<true, true>(sh, s0, l0) : count_walk_lean<true, false>(sh, s0, l0);
-            if (start == POS_INVALID) r.land = POS_INVALID; /* behind END_BLOCK or behind a token the walk of an earlier lane flags */
         } else if (start != POS_INVALID) r = dbl ? count_walk<true, false, true>(sh, start, limit) : count_walk<true>(sh, start, limit);
         else { r.land = POS_INVALID; r.nout = 0; r.flags = 0; r.lastlit = 0; }
         PHASE(4);
