@@ -49,6 +49,8 @@ def load():
     lib.mrcz_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), i32]
     lib.mrcz_debug_fallbacks.restype = ctypes.c_int64
     lib.mrcz_debug_fallbacks.argtypes = [vp]
+    lib.mrcz_debug_chain_fallbacks.restype = ctypes.c_int64
+    lib.mrcz_debug_chain_fallbacks.argtypes = [vp]
     return lib
 
 
@@ -56,7 +58,7 @@ def load():
 EXPORTS = [
     "mrcz_create", "mrcz_destroy", "mrcz_last_error", "mrcz_stream", "mrcz_records_bound",
     "mrcz_compress_chunks", "mrcz_uncompress_chunks", "mrcz_erase_bits", "mrcz_set_timing",
-    "mrcz_last_timings", "mrcz_debug_blocks", "mrcz_debug_fallbacks", "mrcz_debug_inflate_phases", "mrcz_debug_candidates", "mrcz_device_count", "mrcz_dev_malloc", "mrcz_dev_free",
+    "mrcz_last_timings", "mrcz_debug_blocks", "mrcz_debug_fallbacks", "mrcz_debug_chain_fallbacks", "mrcz_debug_inflate_phases", "mrcz_debug_candidates", "mrcz_device_count", "mrcz_dev_malloc", "mrcz_dev_free",
     "mrcz_host_malloc", "mrcz_host_free", "mrcz_copy_h2d", "mrcz_copy_d2h",
     "mrcz_event_create", "mrcz_event_destroy", "mrcz_event_record", "mrcz_stream_wait_event", "mrcz_event_sync",
     "mrcz_copy_h2d_async", "mrcz_copy_d2h_async", "mrcz_compress_chunks_async", "mrcz_uncompress_chunks_async",

@@ -552,6 +552,10 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
         /* real blocks fill at most the planes' size; false candidates and 16-byte rounding get another half */
         ctx->scratch_bytes = (uint64_t)6 * ctx->max_chunks * CHK;
         if (ctx->scratch_bytes > 0xffffffffull * 16ull) ctx->scratch_bytes = 0xffffffffull * 16ull;
+        if (const char *ev = getenv("MRCZ_SCRATCH_BYTES")) { /* tests: a scratch buffer the decoded blocks do not fit in (they must then take the sequential path) */
+            const long long v = atoll(ev);
+            if (v >= 4096 && (uint64_t)v < ctx->scratch_bytes) ctx->scratch_bytes = (uint64_t)v & ~(uint64_t)15;
+        }
         /* 16 bytes of slack on both sides: the merge reads whole 16-byte groups that begin or end in a neighbouring window */
         hipError_t e = hipMalloc((void **)&ctx->scratch, (size_t)ctx->scratch_bytes + 32u);
         if (e != hipSuccess) { ctx->scratch = NULL; return fail(ctx, MRCZ_ENOMEM, "decode scratch", e); }
@@ -593,7 +597,7 @@ static int uncompress_enqueue(mrcz_ctx_t *ctx, const void *d_records, uint64_t l
         LAUNCH("k_chain", k_chain, dim3(ns), dim3(64), rec, len, ctx->dstreams, ctx->cands, ctx->ncand, ctx->segs, ctx->nseg, ctx->segidx,
                ctx->fallback, ctx->phase_profile == 1 ? 1u : 0u, ctx->phase_profile == 4 ? ctx->dbgphase : (unsigned long long *)NULL);
         LAUNCH("k_inflate_par", k_inflate_par, dim3(ns), dim3(PT), rec, len, ctx->dstreams, ctx->planes, ctx->fallback,
-                 ctx->fallback, ctx->phase_profile == 1 ? ctx->dbgphase : (unsigned long long *)NULL);
+                 ctx->fallback, ctx->phase_profile == 1 ? ctx->dbgphase : (unsigned long long *)NULL, ctx->result);
         LAUNCH("k_inflate_seq", k_inflate, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result, ctx->fallback);
         if (ctx->lz4_planes) LAUNCH("k_lz4_blocks", k_lz4_blocks, dim3(ns), dim3(64), rec, ctx->dstreams, ctx->planes, ctx->result);
         LAUNCH("k_merge_segments", k_merge_segments, dim3(512, nb), dim3(256), rec, ctx->scratch + 16, ctx->planes, ctx->segs, ctx->nseg, ctx->segidx, bfl,
@@ -876,6 +880,15 @@ extern "C" int mrcz_debug_candidates(mrcz_ctx_t *ctx, uint64_t out[2])
 }
 
 extern "C" int64_t mrcz_debug_fallbacks(const mrcz_ctx_t *ctx) { return ctx ? (int64_t)ctx->last_fallbacks : -1; }
+/* streams of the last uncompress call whose block chain the parallel path could not close (too many candidates or segments, no
+ * scratch room, static blocks ...) and that k_inflate_par decoded block after block instead */
+extern "C" int64_t mrcz_debug_chain_fallbacks(mrcz_ctx_t *ctx)
+{
+    if (!ctx) return -1;
+    uint64_t v = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMemcpy(&v, ctx->result + 3, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v;
+}
 
 extern "C" int mrcz_debug_blocks(mrcz_ctx_t *ctx, uint32_t stream, mrcz_block_info_t *blocks, uint32_t max_blocks)
 {

@@ -1378,7 +1378,13 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
 /* ======================================================================================
  * kernels
  * ==================================================================================== */
-constexpr int MAXCAND = 1024; /* block-start candidates kept per stream */
+#ifndef MRCZ_MAXCAND
+#define MRCZ_MAXCAND 1024   /* (the sanitizer build of tests/test_sim_fuzz.py lowers the limits so that small inputs run into them) */
+#endif
+#ifndef MRCZ_MAXSEG
+#define MRCZ_MAXSEG 2048
+#endif
+constexpr int MAXCAND = MRCZ_MAXCAND; /* block-start candidates kept per stream */
 constexpr int SCAN_QCAP = 7 * 4 * 64; /* k_scan_candidates: positions of one step waiting for the second test (<= 7 per dword, 4 dwords per lane) */
 /* Survivors of the scan go to one of RAW_SEGS segments of the raw list, each with its own counter: tens of thousands of
  * returning atomics on ONE address serialise in L2 and cost more than the scan itself (measured 0.3 ms of 0.5). */
@@ -2037,7 +2043,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
  * stored block or a whole RAW plane in the records, or (streams the sequential decoders had to take) the plane buffer.
  * k_merge_segments reads the four planes of a tile straight from their segments, so the decoded blocks are never
  * copied to a plane buffer first (that copy was 1.65 GB of traffic per GiB of floats). */
-constexpr int MAXSEG = 2048;            /* segments per stream; a stream that needs more is decoded sequentially */
+constexpr int MAXSEG = MRCZ_MAXSEG;     /* segments per stream; a stream that needs more is decoded sequentially */
 constexpr int MTILE = 4096;             /* plane positions per merge tile */
 constexpr int MTILES = CHK / MTILE;     /* 1536 */
 constexpr uint64_t SEG_REC = 1ull << 62, SEG_PLANES = 1ull << 63, SEG_OFFMASK = (1ull << 62) - 1ull;
@@ -2335,7 +2341,8 @@ __global__ __launch_bounds__(64) void k_chain(const uint8_t *__restrict__ rec, u
 __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ rec, uint64_t reclen,
                                                     const DecStream *__restrict__ ds, uint8_t *__restrict__ planes,
                                                     uint32_t *__restrict__ fallback, const uint32_t *__restrict__ only,
-                                                    unsigned long long *__restrict__ dbg /* NULL, or 20 phase counters per stream */)
+                                                    unsigned long long *__restrict__ dbg /* NULL, or 20 phase counters per stream */,
+                                                    uint64_t *__restrict__ result /* [3] += streams this kernel took over (mrcz_debug_chain_fallbacks) */)
 {
     __shared__ __attribute__((aligned(16))) ParShared sh;
     const int tid = threadIdx.x;
@@ -2343,6 +2350,7 @@ __global__ __launch_bounds__(PT) void k_inflate_par(const uint8_t *__restrict__ 
     const DecStream d = ds[s];
     if (d.raw) return;                  /* RAW planes are read straight from the payload by k_merge_segments */
     if (only && only[s] == 0) return;   /* already decoded block-parallel */
+    if (tid == 0) atomicAdd((unsigned long long *)&result[3], 1ull);
     const StreamView sv = make_view(rec, reclen, d, planes + (size_t)s * CHK);
     if (tid == 0) { sh.cur = 0; sh.op = 0; sh.last = 0; sh.haslit = 0; sh.status = 0; }
     __syncthreads();

@@ -197,6 +197,7 @@ int mrcz_debug_blocks(mrcz_ctx_t *ctx, uint32_t stream, mrcz_block_info_t *block
  * decoder handed to the sequential general-distance decoder (0 for streams this codec or zlib
  * Z_RLE wrote). */
 int64_t mrcz_debug_fallbacks(const mrcz_ctx_t *ctx);
+int64_t mrcz_debug_chain_fallbacks(mrcz_ctx_t *ctx); /* streams of the last uncompress call decoded block after block (chain not closed in parallel) */
 
 /* Inspection (profiling): enable/disable the in-kernel phase counters of the parallel inflate and
  * (if out != NULL) read the 20 counters of `stream` from the last call (shader clocks of thread 0):

@@ -228,6 +228,8 @@ class SimCodec:
         lib.mrcz_last_error.argtypes = [vp]
         lib.mrcz_debug_fallbacks.restype = ctypes.c_int64
         lib.mrcz_debug_fallbacks.argtypes = [vp]
+        lib.mrcz_debug_chain_fallbacks.restype = ctypes.c_int64
+        lib.mrcz_debug_chain_fallbacks.argtypes = [vp]
         self.ctx = vp()
         assert lib.mrcz_create(ctypes.byref(self.ctx), 0, max_batch_chunks) == 0
 
@@ -266,6 +268,7 @@ class SimCodec:
         if rc != 0:
             raise RuntimeError(f"sim uncompress rc={rc}: {self.lib.mrcz_last_error(self.ctx)}")
         self.fallbacks = int(self.lib.mrcz_debug_fallbacks(self.ctx))
+        self.chain_fallbacks = int(self.lib.mrcz_debug_chain_fallbacks(self.ctx))
         return out.copy()
 
 
