@@ -15,7 +15,7 @@ static FILE *open_or_die(const char *path, const char *mode)
     FILE *f = fopen(path, mode);
     if (!f) {
         fprintf(stderr, "[%s:%d] ERROR: fail open:%s\n", __FILE__, __LINE__, path);
-        exit(-1); /* adapt.c:34-44 */
+        mrcz_workers_fatal_exit(); /* adapt.c:34-44 exit(-1); called from a worker thread while the others use the GPU: no exit handlers */
     }
     return f;
 }

@@ -38,7 +38,9 @@ int isTestThroughput = 0; /* src/core/workers.c:39 */
 #define R_OUT 6                   /* pinned output ring */
 #define OUT_SLOT (16u << 20)      /* bytes per output slice */
 #define MAXWRITERS 8
-#define NWRITERS 3                /* threads that pwrite() finished slices (a single thread writes ~5.5 GB/s into the page cache) */
+#define NWRITERS 1                /* threads that pwrite() finished slices.  ONE: tmpfs (and the page cache) serialise the writers of a file on its inode
+                                   * lock, and contending for it is worse than not having it -- tools/shm_write_probe.c on the MI355X box: one thread
+                                   * 8.4 GB/s, two to sixteen threads 3.5-3.8 GB/s into the same file, a MAP_SHARED mapping filled by 4-16 threads 5.6-7.6 */
 #define CHUNK_BYTES ((uint64_t)CHUNK_SIZE * 4u)
 #define IN_SLOT (CHUNK_BYTES + 64u) /* a chunk of floats, or a chunk record (16-byte header + <= 4 RAW planes) */
 
@@ -70,13 +72,18 @@ static int batch_chunks(void) /* MRCZ_BATCH_CHUNKS overrides the default (tests:
  * flag stops the session teardown, stdio is flushed by hand and the process leaves through _exit with the reference's status
  * (exit(-1) = 255). */
 static volatile int g_dying = 0;
+void mrcz_workers_fatal_exit(void) /* (also what the file adapters of adapt_gpu.c leave through: mrc_tarx's worker threads) */
+{
+    g_dying = 1;
+    fflush(stdout);
+    fflush(stderr);
+    _exit(255);
+}
 static void die(const char *what, mrcz_ctx_t *c)
 {
     g_dying = 1;
     fprintf(stderr, "[%s:%d] ERROR: %s: %s\n", __FILE__, __LINE__, what, c ? mrcz_last_error(c) : "");
-    fflush(stdout);
-    fflush(stderr);
-    _exit(255);
+    mrcz_workers_fatal_exit();
 }
 #define CK(call, what, c) do { if ((call) != MRCZ_OK) die(what, c); } while (0)
 
@@ -163,10 +170,10 @@ typedef struct {
     int in_dev[R_IN], out_dev[R_OUT];/* device (index into d[]) that used the slot last */
 } session_t;
 /* Sessions are pooled per first device, at most SESSIONS_PER_DEV of them: a session pins 190 MiB of host memory and holds
- * four device batch buffers, which costs more to set up than a 256 MiB file costs to code, and more than three pipelines in
+ * four device batch buffers, which costs more to set up than a 256 MiB file costs to code, and more than eight pipelines in
  * flight add nothing on one GPU (mrc_tarx -n 8 was slower than -n 2 when every worker thread built its own).  A call takes a
  * free session and gives it back; further callers wait. */
-#define SESSIONS_PER_DEV 3
+#define SESSIONS_PER_DEV 8
 static session_t g_ses[MAXDEV][SESSIONS_PER_DEV];
 static int g_ses_busy[MAXDEV][SESSIONS_PER_DEV];
 static pthread_mutex_t g_ses_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -581,7 +588,7 @@ static void *writer_main(void *arg)
     const uint64_t nd = (uint64_t)p->nd;
     uint64_t oslice = 0; /* output ring position */
     pthread_t pw[MAXWRITERS];
-    int nwr = p->crowd > 2 ? 1 : (p->crowd == 2 ? 2 : NWRITERS);
+    int nwr = NWRITERS;
     if (getenv("MRCZ_WRITERS")) { const int v = atoi(getenv("MRCZ_WRITERS")); if (v >= 1 && v <= MAXWRITERS) nwr = v; }
     const int par = p->fd_out >= 0 && isTestThroughput != 1;
     if (par) {
@@ -754,7 +761,7 @@ int run_compress(FILE *fin, ctx_t *ctx, FILE *fout, const int bitsToMask, const 
     const int int_mode = dataConvertedType && strcmp(dataConvertedType, "int") == 0;
     if (bitsToMask < 0 || bitsToMask > 32) {
         fprintf(stderr, "[%s:%d] ERROR: bits to erase must be in 0..32 (table of 33 masks, workers.c:29-37)\n", __FILE__, __LINE__);
-        exit(-1);
+        mrcz_workers_fatal_exit();
     }
     const double begin = now_sec();
     const uint64_t fsz = get_file_size(fin);
@@ -798,11 +805,11 @@ int run_uncompress(FILE *fin, ctx_t *ctx, mrczip_header_t *hd, FILE *fout, const
     for (int j = 0; j < COMPRESSION_PATH_NUM; j++)
         if (hd->ztypes[j] != 0 && hd->ztypes[j] != 2 && hd->ztypes[j] != 4) { /* ZLIB_DEF, LZ4_DEF, LZ4HC_DEF (mrczip.h:37-40); init_mrc_zip_stream rejects the rest (zip.c:319-321) */
             fprintf(stderr, "[%s:%d] ERROR: byte stream %d uses unknown compressor type %d\n", __FILE__, __LINE__, j, hd->ztypes[j]);
-            exit(-1);
+            mrcz_workers_fatal_exit();
         }
     if (hd->chk == 0 || hd->chk > CHUNK_SIZE) { /* the reference divides by chk (workers.c:589) */
         fprintf(stderr, "[%s:%d] ERROR: bad chunk size %u in header\n", __FILE__, __LINE__, hd->chk);
-        exit(-1);
+        mrcz_workers_fatal_exit();
     }
     const double begin = now_sec();
     const uint64_t nfloats = hd->fsz / COMPRESSION_PATH_NUM; /* workers.c:577 */

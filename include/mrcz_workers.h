@@ -69,6 +69,10 @@ void mrcz_workers_set_device(int device);
  * every device codes its chunk ranges independently and the records are written in file order.  Thread-local, like set_device. */
 void mrcz_workers_set_devices(int first, int ndevices);
 void mrcz_workers_set_batch_chunks(int chunks);
+/* What the library's own fatal errors leave through (the reference's exit(-1), src/core/workers.c:708-712, adapt.c:34-44): stdio
+ * flushed, then _exit(255) -- the errors are raised by pipeline or worker threads while others still use the GPU, and exit
+ * handlers run under them crash instead of exiting. */
+void mrcz_workers_fatal_exit(void);
 
 /* src/include/adapt.h:30-49 */
 int zip_compress(ctx_t *ctx, const char *src, const char *dst, int bitsToLoss);

@@ -291,6 +291,10 @@ def test_damaged_containers_end_with_an_error_status_not_a_signal(tmp_path):
         lst.write_text(str(b) + "\n")
         r = _run([exex, "-i", str(lst), "-t", "unzip", "-o", str(tmp_path), "-n", "2"])
         assert r.returncode > 0, (what, r.returncode, r.stderr)
+    two = tmp_path / "two.txt"                      # two worker threads that both fail to open their output (adapt.c:34-44)
+    two.write_text(str(src) + "\n" + str(src) + "\n")
+    r = _run([exex, "-i", str(two), "-t", "zip", "-o", str(tmp_path / "no" / "such" / "dir"), "-n", "2"])
+    assert r.returncode > 0 and "fail open" in r.stderr, (r.returncode, r.stderr)
     env = dict(os.environ, MRCZ_FULL_TEARDOWN="1")
     assert _run([exe, "-i", str(src), "-o", str(z2), "-b", "8", "-t", "zip"], env=env).returncode == 0
     assert z2.read_bytes() == good

@@ -172,6 +172,11 @@ def test_damaged_containers_end_with_an_error_status_not_a_signal(simbin, tmp_pa
         lst.write_text(str(b) + "\n")
         r = _run([simbin["mrc_tarx"], "-i", str(lst), "-t", "unzip", "-o", str(tmp_path), "-n", "2"])
         assert r.returncode > 0, (what, r.returncode, r.stderr)
+    # two worker threads that both fail to open their output (directory missing, adapt.c:34-44): exit status, not a crash
+    two = tmp_path / "two.txt"
+    two.write_text(str(src) + "\n" + str(src) + "\n")
+    r = _run([simbin["mrc_tarx"], "-i", str(two), "-t", "zip", "-o", str(tmp_path / "no" / "such" / "dir"), "-n", "2"])
+    assert r.returncode > 0 and "fail open" in r.stderr, (r.returncode, r.stderr)
     # the orderly path still releases its sessions: one good run with the full teardown
     r = _run([simbin["mrc_tar"], "-i", str(z), "-o", str(tmp_path / "ok.mrc"), "-t", "unzip"], env={"MRCZ_FULL_TEARDOWN": "1"})
     assert r.returncode == 0 and (tmp_path / "ok.mrc").read_bytes() == util.erase_expected(w, 8).tobytes()
