@@ -1441,7 +1441,14 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
     __shared__ uint32_t stepw[256 + 8];
     __shared__ uint32_t surv[SURV_CAP];
     __shared__ uint32_t sn;
+    __shared__ uint16_t kr3[512]; /* three 3-bit code lengths -> their Kraft sum (in 1/128) | the number of non-zero ones << 12 */
     if (lane == 0) sn = 0;
+    for (uint32_t v = lane; v < 512u; v += 64u) {
+        uint32_t sum = 0, cnt = 0;
+#pragma unroll
+        for (int f = 0; f < 3; f++) { const uint32_t l = (v >> (3 * f)) & 7u; if (l) { sum += 128u >> l; cnt++; } }
+        kr3[v] = (uint16_t)(sum | (cnt << 12));
+    }
     __builtin_amdgcn_wave_barrier();
     const uint32_t seg = (blockIdx.x * 7u + blockIdx.y) % RAW_SEGS, segcap = rawcap / RAW_SEGS;
     /* hand the collected survivors to the raw list: one reservation for the whole wave */
@@ -1534,11 +1541,13 @@ __global__ __launch_bounds__(64) void k_scan_candidates(const uint8_t *__restric
             unsigned long long bits = lo | hi;           /* 64 bits from q: HCLEN(4) then 3-bit lengths */
             const uint32_t ncode = (uint32_t)(bits & 15u) + 4u;
             bits >>= 4;
-            uint32_t kraft = 0, nz = 0;
-            for (uint32_t i = 0; i < ncode; i++) {
-                const uint32_t l = (uint32_t)(bits >> (3u * i)) & 7u;  /* 19 x 3 = 57 bits <= 60 available */
-                if (l) { kraft += 128u >> l; nz++; }
-            }
+            bits &= (1ull << (3u * ncode)) - 1ull;       /* 19 x 3 = 57 bits <= 60 available; lengths behind the last one count as absent */
+            /* Kraft sum and number of codes, three lengths per table look-up (the wave runs this for its slowest lane: a loop over up
+             * to 19 lengths was a third of the kernel's vector instructions) */
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < 7; i++) acc += kr3[(uint32_t)(bits >> (9 * i)) & 511u];
+            const uint32_t kraft = acc & 0xfffu, nz = acc >> 12;
             if (kraft != 128u || nz < 2u) continue;
             const uint32_t i = atomicAdd(&sn, 1u);
             if (i < SURV_CAP) surv[i] = p; /* validated by k_validate_candidates */
