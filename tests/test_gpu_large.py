@@ -57,7 +57,9 @@ def test_one_gib_container_equals_the_oracle(oracle):
     assert rec.numel() == len(ref) - 17 and sum(planes) == rec.numel()
     got = rec.cpu().numpy()
     assert np.array_equal(got, np.frombuffer(ref, np.uint8)[17:]), "the 1 GiB container differs from the oracle's"
-    print("1 GiB config-2 container:", len(ref), "bytes, sha256", util.sha256(ref))
+    import json
+    pin = json.load(open(os.path.join(util.GOLDEN, "golden.json")))["config2_1GiB_b8"]
+    assert (len(ref), util.sha256(ref)) == (pin["container_bytes"], pin["sha256"])          # the size and hash recorded when the test first ran
     out, consumed = big.uncompress_device(rec, n)
     assert consumed == rec.numel() and big.last_fallbacks() == 0
     assert np.array_equal(out.cpu().numpy().view(np.uint32), util.erase_expected(w, 8))   # numpy's erasebytes, not the library's
