@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 import util
 
 SCRIPT = r'''
@@ -73,19 +75,27 @@ print("FUZZ-OK", decoded, rejected)
 '''
 
 
-def test_corrupted_containers_never_touch_foreign_memory(tmp_path):
+@pytest.fixture(scope="module")
+def asan_sim(tmp_path_factory):
+    """The product's HIP sources compiled against the emulator with AddressSanitizer, ONE build for both tests below.  The
+    decoder's per-stream limits are lowered (-DMRCZ_MAXCAND=48 -DMRCZ_MAXSEG=16) so that inputs small enough for the emulator
+    run into them; the fuzz containers (two or three blocks per stream) stay below them."""
     asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
     if not os.path.isabs(asan_rt) or not os.path.exists(asan_rt):
-        import pytest
         pytest.skip("no AddressSanitizer runtime in this image")
-    so = tmp_path / "libmrcz_sim_asan.so"
+    so = tmp_path_factory.mktemp("asan") / "libmrcz_sim_asan.so"
     csrc = os.path.join(util.ROOT, "datacompressionfloat_amd", "csrc")
     subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-I" + util.SIM_DIR, "-I" + csrc, "-Wno-attributes",
-                           "-Wno-unknown-pragmas", "-fsanitize=address", "-fno-omit-frame-pointer", "-shared", "-o", str(so),
+                           "-Wno-unknown-pragmas", "-fsanitize=address", "-fno-omit-frame-pointer", "-DMRCZ_MAXCAND=48", "-DMRCZ_MAXSEG=16", "-shared", "-o", str(so),
                            os.path.join(csrc, "mrcz_api.hip"), os.path.join(util.SIM_DIR, "sim_runtime.cpp")])
+    return str(so), asan_rt
+
+
+def test_corrupted_containers_never_touch_foreign_memory(tmp_path, asan_sim):
+    so, asan_rt = asan_sim
     script = tmp_path / "fuzz.py"
     script.write_text(SCRIPT)
-    env = dict(os.environ, REPO=util.ROOT, SIM_ASAN=str(so), CASES="24", LD_PRELOAD=asan_rt,
+    env = dict(os.environ, REPO=util.ROOT, SIM_ASAN=so, CASES="12", LD_PRELOAD=asan_rt,
                ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1")
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
     assert r.returncode == 0 and "FUZZ-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
@@ -123,8 +133,8 @@ if what == "maxcand":
     planes = [np.zeros(n, np.uint8), rng.integers(0, 256, n, dtype=np.uint64).astype(np.uint8), (rng.integers(0, 16, n) * 17).astype(np.uint8), np.full(n, 0x41, np.uint8)]
     rec = container_records(planes, [0, 0, 1200, 0])
 elif what == "maxseg":
-    # literal-heavy planes of 13 blocks, two windows each: more segments than the build's MAXSEG (16), fewer candidates than MAXCAND
-    n = 400000
+    # literal-heavy planes of 10 blocks, two windows each: more segments than the build's MAXSEG (16), fewer candidates than MAXCAND
+    n = 300000
     planes = [rng.integers(0, 256, n, dtype=np.uint64).astype(np.uint8) for _ in range(2)] + [(rng.integers(0, 200, n)).astype(np.uint8), np.full(n, 0x41, np.uint8)]
     rec = container_records(planes, [0, 0, 0, 0])
 else:
@@ -140,23 +150,15 @@ print("CLIFF-OK", what, sim.chain_fallbacks, sim.fallbacks)
 '''
 
 
-def test_decoder_cliffs_fall_back_with_the_right_bytes(tmp_path):
+def test_decoder_cliffs_fall_back_with_the_right_bytes(tmp_path, asan_sim):
     """Streams that exceed what the block-parallel decoder keeps per stream -- candidates (MAXCAND), segments (MAXSEG), scratch
     room -- must come out of k_inflate_par / k_inflate byte for byte.  The sanitizer build lowers the limits (-DMRCZ_MAXCAND=48
     -DMRCZ_MAXSEG=16, MRCZ_SCRATCH_BYTES) so that inputs small enough for the emulator run into them."""
-    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
-    if not os.path.isabs(asan_rt) or not os.path.exists(asan_rt):
-        import pytest
-        pytest.skip("no AddressSanitizer runtime in this image")
-    so = tmp_path / "libmrcz_sim_cliff.so"
-    csrc = os.path.join(util.ROOT, "datacompressionfloat_amd", "csrc")
-    subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-I" + util.SIM_DIR, "-I" + csrc, "-Wno-attributes",
-                           "-Wno-unknown-pragmas", "-fsanitize=address", "-fno-omit-frame-pointer", "-DMRCZ_MAXCAND=48", "-DMRCZ_MAXSEG=16", "-shared", "-o", str(so),
-                           os.path.join(csrc, "mrcz_api.hip"), os.path.join(util.SIM_DIR, "sim_runtime.cpp")])
+    so, asan_rt = asan_sim
     script = tmp_path / "cliff.py"
     script.write_text(CLIFF_SCRIPT)
     for what in ("maxcand", "maxseg", "scratch"):
-        env = dict(os.environ, REPO=util.ROOT, SIM_ASAN=str(so), CLIFF=what, LD_PRELOAD=asan_rt,
+        env = dict(os.environ, REPO=util.ROOT, SIM_ASAN=so, CLIFF=what, LD_PRELOAD=asan_rt,
                    ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1")
         if what == "scratch":
             env["MRCZ_SCRATCH_BYTES"] = "8192"
