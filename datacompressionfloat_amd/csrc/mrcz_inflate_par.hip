@@ -269,8 +269,9 @@ __device__ __forceinline__ uint32_t tok_bits(const ParShared &sh, uint32_t idx) 
 
 /* total bits of the token that starts at the low bit of v (>= 33 valid bits): 1..MAXTOK, or
  * X_EOB (END_BLOCK) / X_ERR (invalid, or a token the parallel path does not resolve) */
-__device__ __noinline__ uint32_t token_bits(const ParShared &sh, unsigned long long v)
+__device__ __noinline__ uint32_t token_bits(const ParShared &sh, unsigned long long v0, uint32_t shift /* the token starts at bit `shift` of v0 (shifted here: at the call it would be hoisted into P1's hot path) */)
 {
+    const unsigned long long v = v0 >> shift;
     const uint32_t d = huff_decode_lit(sh, (uint32_t)v);
     if (d == 0xffffffffu) return X_ERR;
     const uint32_t l = d >> 16, sym = d & 0xffffu;
@@ -374,6 +375,18 @@ __device__ __forceinline__ uint32_t ring_off(uint32_t x)
     static_assert(PT * 4 == 2048, "ring_off assumes 2 KiB rows");
     return (x * 0x201u) & 0x3803u;
 }
+/* a * b + c as ONE v_mad_u32_u24 with b in a vector and c in a scalar register (a, b < 2^24).  Written as C, the compiler turns
+ * (t * 0x201 + c) into shift-add + add: P1 does this once per bit position of the stream. */
+__device__ __forceinline__ uint32_t mad24_vs(uint32_t a, uint32_t vb, uint32_t sc)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(vb), "s"(sc));
+    return r;
+#else
+    return a * vb + sc;
+#endif
+}
 template <bool TAIL, bool MIN4, bool COMPLETE>
 __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int wq, uint32_t lead, uint32_t nw /* dwords per piece */)
 {
@@ -388,6 +401,10 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
     const uint8_t *tokb = reinterpret_cast<const uint8_t *>(sh.tok);
     const uint8_t *ringb = reinterpret_cast<const uint8_t *>(&sh.ring[0][0]);
     const uint32_t lane4 = tid << 2; /* my column: bits 2..10 of a ring byte offset (row = bits 11..13, byte = bits 0..1) */
+    uint32_t k201 = 0x201u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(k201)); /* (kept in a register: see mad24_vs) */
+#endif
 #pragma unroll
     for (int q = 7; q >= 0; q--) {
         /* A token is at most MAXTOK = 24 bits, so while the group of positions k .. k+3 is processed the ring row of positions
@@ -404,19 +421,21 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
             tt[j] = tokb[off]; /* byte 0 of the entry: token bits */
         }
         if (!COMPLETE) { /* some table entries say "ask token_bits()" (codes longer than the index, matches that do not fit in it) */
-            if ((tt[0] == 0u) | (tt[1] == 0u) | (tt[2] == 0u) | (tt[3] == 0u)) {
+            const uint32_t m01 = tt[0] < tt[1] ? tt[0] : tt[1], m23 = tt[2] < tt[3] ? tt[2] : tt[3];
+            if ((m01 < m23 ? m01 : m23) == 0u) { /* (min3 + min + one compare instead of four compares) */
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (tt[j] == 0u) tt[j] = token_bits(sh, w01 >> (4 * q + j));
+                    if (tt[j] == 0u) tt[j] = token_bits(sh, w01, (uint32_t)(4 * q + j));
             }
         }
         uint32_t ex[4], x[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             x[j] = kbase + (uint32_t)(4 * q + j) + tt[j];
-            /* ring_off(x) with the position's part folded into a wave-uniform constant */
-            const uint32_t c = (kbase + (uint32_t)(4 * q + j)) * 0x201u;
-            ex[j] = ringb[((tt[j] * 0x201u + c) & 0x3803u) | lane4];
+            /* ring_off(x) with the position's part folded into a constant.  kbase drops out: it is a multiple of 32, and
+             * 32 w * 0x201 = w << 5 | w << 14 reaches none of the bits the mask keeps (the low part, y + (w << 5) with y < 64
+             * and w < 8, stays below bit 9) */
+            ex[j] = ringb[(mad24_vs(tt[j], k201, (uint32_t)(4 * q + j) * 0x201u) & 0x3803u) | lane4];
         }
         if (TAIL) {
 #pragma unroll
@@ -433,7 +452,8 @@ __device__ __forceinline__ void piece_exit_word(ParShared &sh, uint32_t tid, int
             if (tt[0] == 2u) ex[0] = ex[2];
             if (tt[0] == 3u) ex[0] = ex[3];
         }
-        sh.ring[q][tid] = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (ex[3] << 24); /* positions kbase + 4q .. + 3 */
+        /* positions kbase + 4q .. + 3, packed by three byte permutes (the shift-and-or form compiles to four instructions) */
+        sh.ring[q][tid] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(ex[3], ex[2], 0x0c0c0400u), __builtin_amdgcn_perm(ex[1], ex[0], 0x0c0c0400u), 0x05040100u);
     }
 }
 template <bool MIN4, bool COMPLETE>
@@ -510,6 +530,8 @@ __device__ __noinline__ uint32_t count_general_token(const ParShared &sh, uint32
         nb = 64 - (int)((pos_) & 31u);                                                                                \
         wi += 2;                                                                                                      \
     } while (0)
+#define WALK_BITS_REFILL(pos_) if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
+#define WALK_TOK() sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)]
 
 /* P3: count walk.  Decode tokens from window bit `start` until the position reaches `limit` (or
  * END_BLOCK), counting the plane bytes they produce.  Nearly every token is sized by ONE 12-bit lookup. */
@@ -522,8 +544,8 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
     uint32_t laste = 0; /* table entry of the last literal decoded (its byte is taken out once, behind the loop) */
     WALK_BITS_INIT(pos);
     while (pos < limit) {
-        if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
-        const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
+        WALK_BITS_REFILL(pos);
+        const uint32_t e = WALK_TOK();
         if ((int32_t)e >= 0) { /* 1 <= token bits <= MAXTOK, distance 1 */
             const uint32_t t = e & 0xffu;
             if (DBL && (e & TOK_PAIR)) { /* two literals */
@@ -572,8 +594,8 @@ __device__ __forceinline__ SubResult stage_walk(ParShared &sh, uint32_t start, u
     uint32_t cnt = 0, accw = 0, slow = 0, laste = 0;
     WALK_BITS_INIT(pos);
     while (pos < limit) {
-        if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
-        const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
+        WALK_BITS_REFILL(pos);
+        const uint32_t e = WALK_TOK();
         if ((int32_t)e >= 0) {
             const uint32_t t = e & 0xffu, n = (e >> TOK_N_SHIFT) & 0x1ffu;
             buf >>= t; nb -= (int)t; pos += t;
@@ -689,8 +711,8 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
     for (;;) {
         if (rem == 0u) {
             if (pos >= limit) break;
-            if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
-            const uint32_t e = sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)];
+            WALK_BITS_REFILL(pos);
+            const uint32_t e = WALK_TOK();
             uint32_t n;
             if ((int32_t)e >= 0) { /* 1 <= token bits <= MAXTOK, distance 1 */
                 uint32_t t = e & 0xffu;

@@ -165,6 +165,21 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return sim_exchange(v, lane & 63); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return sim_exchange(v, 0); }
+/* v_perm_b32: result byte i = byte sel[i] of (s0 : s1) (0..3 = s1, 4..7 = s0), 0x0c = 0x00, >= 0x0d = 0xff */
+static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+    const uint64_t v = ((uint64_t)s0 << 32) | s1;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t b = (sel >> (8 * i)) & 0xffu;
+        uint32_t x;
+        if (b <= 7u) x = (uint32_t)(v >> (8u * b)) & 0xffu;
+        else if (b <= 11u) x = ((v >> (16u * (b - 8u) + 15u)) & 1u) ? 0xffu : 0u; /* sign of word b - 8 */
+        else x = b == 12u ? 0u : 0xffu;
+        r |= x << (8 * i);
+    }
+    return r;
+}
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
 /* DPP move, the controls the product uses: row_shr:n (0x110 + n), row_shl:n (0x100 + n), row_bcast:15 (0x142), row_bcast:31 (0x143),
  * wave_shr:1 (0x138), wave_shl:1 (0x130); a lane whose row is
