@@ -2469,71 +2469,87 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint8_t *__restric
     const uint32_t ns = nseg[s];
     SegBases sb;
     sb.rec = rec; sb.scratch = scratch; sb.planes = planes; sb.reclen = reclen; sb.planes_bytes = planes_bytes;
-    /* nearly every tile lies in one segment or two: both are fetched with wave-uniform (scalar) loads.  Tile -> segment number
-     * -> segment -> data is a chain of three memory round trips, so the segments of the NEXT tile are looked up while this
-     * tile's data is in flight. */
+    /* nearly every tile lies in one to three segments (three: a block of 4-bit codes is 32767 x 4.06 bits = a full window of 16 KiB
+     * and a stub of 500 bytes, so every eighth tile of such a plane has a stub in its middle): they are fetched with wave-uniform
+     * (scalar) loads.  Tile -> segment number -> segment -> data is a chain of three memory round trips, so the segments of the
+     * NEXT tile are looked up while this tile's data is in flight. */
+    constexpr int NSEGF = 3; /* segments per tile on the fast path */
     Seg ZS;
     ZS.src = 0; ZS.dst = 0; ZS.len = 0; ZS.fill_until = 0; ZS.fillb = 0;
     uint32_t k0n = 0;
-    Seg An = ZS, Bn = ZS;
+    Seg Sn[NSEGF];
+#pragma unroll
+    for (int i = 0; i < NSEGF; i++) Sn[i] = ZS;
     if ((uint64_t)blockIdx.x * MTILE < n) {
         k0n = ns ? (uint32_t)__builtin_amdgcn_readfirstlane((int)segidx[(size_t)s * MTILES + blockIdx.x]) : 0u;
-        if (k0n < ns) An = sg[k0n];
-        if (k0n + 1u < ns) Bn = sg[k0n + 1u];
+#pragma unroll
+        for (int i = 0; i < NSEGF; i++) if (k0n + (uint32_t)i < ns) Sn[i] = sg[k0n + (uint32_t)i];
     }
     for (uint32_t t = blockIdx.x; (uint64_t)t * MTILE < n; t += gridDim.x) {
         const uint32_t p0 = t * MTILE, pend = (n - p0) < (uint32_t)MTILE ? n : p0 + MTILE;
         const uint32_t k0 = k0n;
-        const Seg A = An, B = Bn;
+        Seg S[NSEGF];
+        const uint8_t *base[NSEGF];
+        uint32_t send[NSEGF];
+#pragma unroll
+        for (int i = 0; i < NSEGF; i++) { S[i] = Sn[i]; base[i] = seg_base(sb, S[i].src); send[i] = S[i].dst + S[i].len; }
         const uint32_t tn = t + gridDim.x;
         const bool more = (uint64_t)tn * MTILE < n;
         if (more) k0n = ns ? (uint32_t)__builtin_amdgcn_readfirstlane((int)segidx[(size_t)s * MTILES + tn]) : 0u;
-        const uint8_t *abase = seg_base(sb, A.src), *bbase = seg_base(sb, B.src);
-        const uint32_t aend = A.dst + A.len, bend = B.dst + B.len;
-        /* A group of 16 bytes that straddles the boundary A | B (one per boundary) is read twice -- once relative to each
-         * segment, reading a few bytes past A's end and before B's start -- and blended: no byte loop, no dependent loads.
-         * Fill bytes near the boundary and sources that cannot be over-read (ends of the records) take the general path. */
-        const bool adj = B.len != 0u && B.dst == aend && A.len != 0u;
+        /* A group of 16 bytes that straddles a boundary X | Y of two consecutive segments (one per boundary) is read twice --
+         * once relative to each segment, reading a few bytes past X's end and before Y's start -- and blended: no byte loop, no
+         * dependent loads.  Fill bytes near the boundary, groups over more than two segments and sources that cannot be over-read
+         * (ends of the records) take the general path. */
+        bool adj[NSEGF - 1];
+#pragma unroll
+        for (int i = 0; i + 1 < NSEGF; i++) adj[i] = S[i + 1].len != 0u && S[i + 1].dst == send[i] && S[i].len != 0u;
         /* four independent 16-byte loads per lane first (destination-aligned groups, source at any alignment), patches after */
-        uint4 v[MTILE / 16 / 64], v2 = make_uint4(0, 0, 0, 0); /* (one boundary A | B: at most one straddling group per lane) */
-        uint32_t kind[MTILE / 16 / 64]; /* 0 zero, 1 inside A, 2 inside B, 3 straddles A | B, 4 general path, 5 / 6 inside A's / B's fill */
+        uint4 v[MTILE / 16 / 64], v2[MTILE / 16 / 64];
+        uint32_t kind[MTILE / 16 / 64]; /* 0 zero, 1 inside a segment, 3 straddles two, 4 general path, 5 inside a segment's fill; | segment number << 4 */
 #pragma unroll
         for (int j = 0; j < MTILE / 16 / 64; j++) {
             const uint32_t g = (uint32_t)lane + 64u * (uint32_t)j, p = p0 + 16u * g;
             const bool whole = ns != 0u && p + 16u <= pend;
-            const bool inA = p >= A.dst && p + 16u <= aend, inB = p >= B.dst && p + 16u <= bend;
             uint32_t kd = (p < pend && ns) ? 4u : 0u;
-            if (whole && inA) kd = 1u;
-            else if (whole && inB) kd = 2u;
-            else if (whole && adj && p >= A.dst && p < aend && p + 16u <= bend && p >= A.fill_until && B.fill_until <= B.dst &&
-                     seg_can_overread(sb, A.src, (int64_t)(p - A.dst)) && seg_can_overread(sb, B.src, (int64_t)p - (int64_t)B.dst)) kd = 3u;
+            v[j] = make_uint4(0, 0, 0, 0);
+            v2[j] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = NSEGF - 1; i >= 0; i--) { /* (the segments of a tile do not overlap: at most one of these holds) */
+                if (whole && p >= S[i].dst && p + 16u <= send[i]) kd = (p + 16u <= S[i].fill_until ? 5u : 1u) | ((uint32_t)i << 4);
+            }
+#pragma unroll
+            for (int i = NSEGF - 2; i >= 0; i--) {
+                if (kd == 4u && whole && adj[i] && p >= S[i].dst && p < send[i] && p + 16u <= send[i + 1] && p >= S[i].fill_until && S[i + 1].fill_until <= S[i + 1].dst &&
+                    seg_can_overread(sb, S[i].src, (int64_t)(p - S[i].dst)) && seg_can_overread(sb, S[i + 1].src, (int64_t)p - (int64_t)S[i + 1].dst)) kd = 3u | ((uint32_t)i << 4);
+            }
             /* a group that lies inside a segment's fill (leading repeats of a block, a window of equal bytes that was never
              * written) is not loaded at all */
-            if (kd == 1u && p + 16u <= A.fill_until) kd = 5u;
-            if (kd == 2u && p + 16u <= B.fill_until) kd = 6u;
             kind[j] = kd;
-            v[j] = make_uint4(0, 0, 0, 0);
-            if (kd == 1u || kd == 3u) __builtin_memcpy(&v[j], abase + (p - A.dst), 16);
-            if (kd == 2u) __builtin_memcpy(&v[j], bbase + (p - B.dst), 16);
-            if (kd == 3u) __builtin_memcpy(&v2, bbase + ((int64_t)p - (int64_t)B.dst), 16);
+#pragma unroll
+            for (int i = 0; i < NSEGF; i++) {
+                if (kd == (1u | ((uint32_t)i << 4)) || kd == (3u | ((uint32_t)i << 4))) __builtin_memcpy(&v[j], base[i] + (p - S[i].dst), 16);
+                if (i + 1 < NSEGF && kd == (3u | ((uint32_t)i << 4))) __builtin_memcpy(&v2[j], base[i + 1] + ((int64_t)p - (int64_t)S[i + 1].dst), 16);
+            }
         }
-        An = ZS; Bn = ZS;
-        if (more && k0n < ns) An = sg[k0n];
-        if (more && k0n + 1u < ns) Bn = sg[k0n + 1u];
+#pragma unroll
+        for (int i = 0; i < NSEGF; i++) { Sn[i] = ZS; if (more && k0n + (uint32_t)i < ns) Sn[i] = sg[k0n + (uint32_t)i]; }
 #pragma unroll
         for (int j = 0; j < MTILE / 16 / 64; j++) {
             const uint32_t g = (uint32_t)lane + 64u * (uint32_t)j, p = p0 + 16u * g;
-            if (kind[j] == 1u || kind[j] == 2u) {
-                const uint32_t fu = kind[j] == 1u ? A.fill_until : B.fill_until;
+            const uint32_t kd = kind[j] & 15u, si = kind[j] >> 4;
+            uint32_t fu = 0, fb = 0, se = 0;
+#pragma unroll
+            for (int i = 0; i < NSEGF; i++) if (si == (uint32_t)i) { fu = S[i].fill_until; fb = S[i].fillb & 0xffu; se = send[i]; }
+            if (kd == 1u) {
                 if (p < fu) { /* leading repeats of a block: the previous block's last byte */
-                    const uint32_t fw = 0x01010101u * ((kind[j] == 1u ? A.fillb : B.fillb) & 0xffu);
+                    const uint32_t fw = 0x01010101u * fb;
                     v[j] = blend16(make_uint4(fw, fw, fw, fw), v[j], fu - p >= 16u ? 16u : fu - p);
                 }
-            } else if (kind[j] == 5u || kind[j] == 6u) {
-                const uint32_t fw = 0x01010101u * ((kind[j] == 5u ? A.fillb : B.fillb) & 0xffu);
+            } else if (kd == 5u) {
+                const uint32_t fw = 0x01010101u * fb;
                 v[j] = make_uint4(fw, fw, fw, fw);
-            } else if (kind[j] == 3u) v[j] = blend16(v[j], v2, aend - p);
-            else if (kind[j] == 4u) v[j] = merge_slow16(sb, sg, ns, p, pend, k0);
+            } else if (kd == 3u) v[j] = blend16(v[j], v2[j], se - p);
+            else if (kd == 4u) v[j] = merge_slow16(sb, sg, ns, p, pend, k0);
             tile[w][g] = v[j];
         }
         __syncthreads();
