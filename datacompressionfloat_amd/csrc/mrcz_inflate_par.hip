@@ -128,10 +128,9 @@ struct ParShared {
     uint32_t nwin;      /* windows of the current block so far */
     unsigned long long acc[20], tp; /* phase counters (profiling builds of the call only) */
     uint32_t dbl;       /* enough table entries carry a second literal for the walks to look for it (block of short codes) */
+    uint32_t ndbl;      /* table entries that could carry a second literal (counted while the block's tables are built) */
     uint32_t complete;  /* every entry of the token table carries its token's bits (no entry says "ask token_bits()") */
-    uint32_t dmax;      /* longest distance code + extra bits of the current block */
     uint32_t mintok;    /* shortest literal/length code of the current block (every token is at least that long) */
-    uint32_t maxtok;    /* longest token of the current block, bits (<= MAXTOK on the parallel path) */
 };
 
 /* ---- sequential bit reader over LDS words (header parsing, thread 0) ---- */
@@ -330,6 +329,9 @@ __device__ __forceinline__ void tok_table_build(ParShared &sh, int tid, uint32_t
         uint32_t cov = 0; /* patterns owned by the codes of <= LBITS bits */
         for (int len = 1; len <= LBITS; len++) cov += (uint32_t)sh.lit.count[len] << (LBITS - len);
         sh.complete = cov == (1u << LBITS) ? 1u : 0u;
+        uint32_t mt = 15;
+        for (int len = 15; len >= 1; len--) if (sh.lit.count[len]) mt = (uint32_t)len;
+        sh.mintok = mt;
     }
     __syncthreads();
     bool zero = false;
@@ -1064,7 +1066,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
 {
     constexpr bool WRITE = MODE == MODE_FINAL;
     uint32_t widx = 0; /* window number inside the block */
-    if (tid == 0) { sh.nwin = 0; sh.lead = 0; sh.dbl = 0; }
+    if (tid == 0) { sh.nwin = 0; sh.lead = 0; sh.dbl = 0; sh.ndbl = 0; }
     const bool hdr_cached = hc != nullptr && hc->valid == hctag;
     if (hdr_cached) {
         if (tid == 0) { sh.btype = 2; sh.bfinal = hc->bfinal; sh.nlen = hc->nlen; sh.ndist = hc->ndist; sh.cur = hc->cur_after; }
@@ -1180,37 +1182,20 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
                     if (l2 != 0u && t + l2 <= (uint32_t)LBITS && sym2 < 256u) { second[k] = TOK_PAIR | (l2 << TOK_LEN_SHIFT) | (sym2 << TOK_B2_SHIFT); ndbl++; }
                 }
             }
-            if (ndbl) atomicAdd(&sh.dbl, ndbl);
+            if (ndbl) atomicAdd(&sh.ndbl, ndbl);
             __syncthreads();
             /* worth the walks' extra test when a quarter of the patterns are pairs; otherwise the table stays as the plain walks read it */
-            pairs = sh.dbl >= (1u << LBITS) / 4u;
+            pairs = sh.ndbl >= (1u << LBITS) / 4u;
             if (pairs) {
 #pragma unroll
                 for (int k = 0; k < EPT; k++)
                     if (second[k]) sh.tok[tid + k * PT] = (sh.tok[tid + k * PT] & ~(15u << TOK_LEN_SHIFT)) | second[k];
             }
-            __syncthreads();
+            /* (no barrier: the table is next read behind the first window's staging barrier, and the count has its own word) */
         }
         if (tid == 0) sh.dbl = pairs ? 1u : 0u;
     }
-    /* longest token of this block: bounds the exit-function domain */
-    if (tid == 0) { sh.dmax = 0; sh.maxtok = 1; sh.mintok = 15; }
-    __syncthreads();
-    if ((uint32_t)tid < sh.ndist) {
-        const uint32_t dl = sh.lens[sh.nlen + tid];
-        if (dl) atomicMax(&sh.dmax, dl + ((uint32_t)tid < 4u ? 0u : ((uint32_t)tid >> 1) - 1u));
-    }
-    __syncthreads();
-    if ((uint32_t)tid < sh.nlen) {
-        const uint32_t ll = sh.lens[tid];
-        if (ll) atomicMin(&sh.mintok, ll);
-        if (ll) atomicMax(&sh.maxtok, tid < 257 ? ll : ll + (uint32_t)len_extra_bits(tid - 257 < 29 ? tid - 257 : 0) + sh.dmax);
-    }
-    __syncthreads();
-    if (tid == 0 && sh.maxtok > (uint32_t)MAXTOK) sh.maxtok = MAXTOK;
-    __syncthreads();
-
-
+    /* (sh.mintok comes out of tok_table_build; the first window's staging barrier publishes what thread 0 wrote above) */
     PHASE(0);
     /* ---------------- block body, window by window ---------------- */
     for (;;) {
