@@ -218,6 +218,33 @@ __device__ __forceinline__ void huff_build(H &h, const uint8_t *lens, int n, int
     }
     __syncthreads();
 }
+/* first codes, offsets into the sorted list and limits of one code from the per-wave length counts: ONE wave, no workgroup barrier
+ * (lane len sums its length's counts; the running code is a recurrence over the lengths, every lane follows it with lane reads) */
+template <class H>
+__device__ __forceinline__ void huff_tables_wave(H &h, int lane, int nwaves)
+{
+    uint32_t c = 0;
+    if (lane >= 1 && lane < 16) for (int ww = 0; ww < nwaves; ww++) c += h.wcnt[ww][lane];
+    if (lane < 16) h.count[lane] = (uint16_t)c;
+    uint32_t code = 0, idx = 0;
+    for (int len = 1; len <= 15; len++) {
+        const uint32_t cl = (uint32_t)__shfl((int)c, len);
+        if (lane == len) {
+            h.first[len] = (uint16_t)code;
+            h.offs[len] = (uint16_t)idx;
+            /* codes of this length, left-justified to 15 bits, are < limit[len] (non-decreasing in len) */
+            const uint32_t lim = (code + cl) << (15 - len);
+            h.limit[len] = (uint16_t)(lim > 0x7fffu ? 0x8000u : lim);
+        }
+        code = (code + cl) << 1;
+        idx += cl;
+    }
+}
+/* huff_core for the literal/length code (symbol t by thread t, waves 0..4) and the distance code (symbol t - 320 by thread t:
+ * wave 5) of a block TOGETHER: three barriers instead of the eight of two huff_core calls -- a block's tables are a chain of
+ * short phases, and what they cost is their barriers.  Returns the canonical code of the thread's literal/length symbol. */
+struct ParShared;
+__device__ __forceinline__ uint32_t huff_core_litdist(ParShared &sh, int tid);
 /* decode one symbol from the low bits of v (>= 15 valid bits); returns sym | len << 16, or 0xffffffff.
  * Codes longer than the table's index bits are resolved by comparing the left-justified 15-bit
  * prefix against the per-length limits (canonical codes are ordered by length), not by a bit loop. */
@@ -288,6 +315,57 @@ __device__ __noinline__ uint32_t token_bits(const ParShared &sh, unsigned long l
     return t > (uint32_t)MAXTOK ? X_ERR : t;
 }
 
+__device__ __forceinline__ uint32_t huff_core_litdist(ParShared &sh, int tid)
+{
+    static_assert(PT >= 384 && HuffAux::NW == 5, "waves 0..4 own the literal/length symbols, wave 5 the distance symbols");
+    const int w = tid >> 6, l = tid & 63;
+    const int nl = (int)sh.nlen, nd = (int)sh.ndist;
+    const bool isd = w == 5;
+    int mylen = 0;
+    if (isd) { if (l < nd) mylen = sh.lens[nl + l]; }
+    else if (tid < nl) mylen = sh.lens[tid];
+    int rank = 0;
+    for (int len = 1; len <= 15; len++) {
+        const unsigned long long m = __ballot(mylen == len);
+        if (mylen == len) rank = __builtin_popcountll(m & ((1ull << l) - 1ull));
+        if (l == 0) {
+            if (w < HuffAux::NW) sh.lit.wcnt[w][len] = (uint16_t)__builtin_popcountll(m);
+            else if (isd) sh.dist.wcnt[0][len] = (uint16_t)__builtin_popcountll(m);
+        }
+    }
+    __syncthreads();
+    if (w == 0) huff_tables_wave(sh.lit, l, (nl + 63) >> 6);
+    else if (w == 1) huff_tables_wave(sh.dist, l, 1);
+    __syncthreads();
+    uint32_t code = 0;
+    if (mylen) {
+        if (isd) sh.dist.sorted[sh.dist.offs[mylen] + (uint32_t)rank] = (uint16_t)l;
+        else {
+            uint32_t base = 0;
+            for (int ww = 0; ww < w; ww++) base += sh.lit.wcnt[ww][mylen];
+            const uint32_t r = base + (uint32_t)rank;
+            sh.lit.sorted[sh.lit.offs[mylen] + r] = (uint16_t)tid;
+            code = (uint32_t)sh.lit.first[mylen] + r;
+        }
+    }
+    __syncthreads();
+    return code;
+}
+/* the distance code's fast table (1 << DBITS entries, one per thread; the caller's next barrier publishes it) */
+__device__ __forceinline__ void dist_lut_fill(ParShared &sh, int tid)
+{
+    for (uint32_t idx = (uint32_t)tid; idx < (1u << DBITS); idx += PT) {
+        const uint32_t x = (__brev(idx) >> (32 - DBITS)) << (15 - DBITS); /* left-justified 15-bit prefix */
+        int len = 0;
+        for (int k = DBITS; k >= 1; k--) if (x < sh.dist.limit[k]) len = k; /* smallest k with x < limit[k] */
+        uint32_t e = 0;
+        if (len) {
+            const uint32_t d = (x >> (15 - len)) - sh.dist.first[len];
+            if (d < sh.dist.count[len]) e = (uint32_t)sh.dist.sorted[sh.dist.offs[len] + d] | ((uint32_t)len << 9);
+        }
+        sh.dist.lut[idx] = (uint16_t)e;
+    }
+}
 /* entry of the token table for the LBITS-bit pattern idx, which starts with the code (l bits) of literal/length symbol sym: the
  * token's total bits when the pattern determines them (a literal or END_BLOCK, or a match whose extra bits and distance CODE
  * fit in what is left of the pattern), else token bits 0 = "ask token_bits()"; TOK_SLOW on everything the walks do not take in
@@ -325,6 +403,7 @@ __device__ __forceinline__ void tok_table_build(ParShared &sh, int tid, uint32_t
     constexpr int EPT = (1 << LBITS) / PT;
 #pragma unroll
     for (int k = 0; k < EPT; k++) sh.tok[tid + k * PT] = TOK_SLOW;
+    dist_lut_fill(sh, tid); /* (tok_entry reads it: behind the barrier below) */
     if (tid == 0) {
         uint32_t cov = 0; /* patterns owned by the codes of <= LBITS bits */
         for (int len = 1; len <= LBITS; len++) cov += (uint32_t)sh.lit.count[len] << (LBITS - len);
@@ -1157,9 +1236,8 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
 #ifndef EXP_DOUBLE
 #define EXP_DOUBLE 0
 #endif
-    const uint32_t mycode = huff_core(sh.lit, sh.lens, (int)sh.nlen, tid);
+    const uint32_t mycode = huff_core_litdist(sh, tid);
     PHASE(15);
-    huff_build<0, 9>(sh.dist, sh.lens + sh.nlen, (int)sh.ndist, tid, sh.dist.lut, DBITS);
     PHASE(16);
     if (EXP_DOUBLE & 4) tok_table_build(sh, tid, mycode); /* what-if timing builds only */
     tok_table_build(sh, tid, mycode);
