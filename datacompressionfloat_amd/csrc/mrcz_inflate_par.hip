@@ -97,6 +97,11 @@ constexpr uint32_t TOK_SLOW = 1u << 31;
 __device__ __forceinline__ uint32_t tok_second_len(uint32_t e) { return (e & TOK_PAIR) ? (e >> TOK_LEN_SHIFT) & 15u : 0u; }
 
 
+/* a value every lane of the wave holds (read from LDS or global memory, so the compiler cannot know): one v_readfirstlane moves it to
+ * a scalar register, and everything computed from it -- addresses, loop bounds, branch conditions -- follows it there, off the
+ * vector registers this kernel is short of (80 per lane at three workgroups per CU) */
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 struct ParShared {
     uint32_t win[WIN_WORDS];
     unsigned long long fnlo[PT / 64], fnhi[PT / 64]; /* exit function of each wave (header pieces) */
@@ -869,6 +874,7 @@ __device__ __forceinline__ uint32_t block_excl_last_pt(uint32_t v, uint32_t *wto
     __syncthreads();
     return e ? e : pre;
 }
+template <bool REUSE_BARRIER = true /* false: the caller passes another barrier before wtot[] is written again */>
 __device__ __forceinline__ uint32_t block_min_pt(uint32_t v, uint32_t *wtot)
 {
     const int l = lane_id(), w = threadIdx.x >> 6;
@@ -878,7 +884,7 @@ __device__ __forceinline__ uint32_t block_min_pt(uint32_t v, uint32_t *wtot)
     __syncthreads();
     uint32_t r = 0xffffffffu;
     for (int i = 0; i < PT / 64; i++) { const uint32_t t = wtot[i]; r = t < r ? t : r; }
-    __syncthreads();
+    if (REUSE_BARRIER) __syncthreads();
     return r;
 }
 
@@ -1146,7 +1152,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
     constexpr bool WRITE = MODE == MODE_FINAL;
     uint32_t widx = 0; /* window number inside the block */
     if (tid == 0) { sh.nwin = 0; sh.lead = 0; sh.dbl = 0; sh.ndbl = 0; }
-    const bool hdr_cached = hc != nullptr && hc->valid == hctag;
+    const bool hdr_cached = hc != nullptr && uni(hc->valid) == hctag;
     if (hdr_cached) {
         if (tid == 0) { sh.btype = 2; sh.bfinal = hc->bfinal; sh.nlen = hc->nlen; sh.ndist = hc->ndist; sh.cur = hc->cur_after; }
         if (tid < 320) sh.lens[tid] = hc->lens[tid];
@@ -1278,7 +1284,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
     /* ---------------- block body, window by window ---------------- */
     for (;;) {
         if (dbg && tid == 0) sh.acc[11]++;
-        const uint32_t wcur = sh.cur;
+        const uint32_t wcur = uni(sh.cur);
         /* Piece size of this window: a window's time is ONE lane's serial work on its piece, whatever the number of pieces
          * that hold tokens.  When the block probably ends inside the window (the next candidate's start bit is the hint),
          * what is left of it is spread over all PT lanes in pieces of fewer dwords.  A wrong hint costs time, not
@@ -1299,11 +1305,12 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
                 if (sh.mintok >= 4u) piece_exit_lds<true, false>(sh, (uint32_t)tid, wlead, nw);
                 else piece_exit_lds<false, false>(sh, (uint32_t)tid, wlead, nw);
             }
-            if (sh.complete) {
-                if (sh.mintok >= 4u) piece_exit_lds<true, true>(sh, (uint32_t)tid, wlead, nw);
+            const bool min4 = uni(sh.mintok) >= 4u;
+            if (uni(sh.complete)) {
+                if (min4) piece_exit_lds<true, true>(sh, (uint32_t)tid, wlead, nw);
                 else piece_exit_lds<false, true>(sh, (uint32_t)tid, wlead, nw);
             } else {
-                if (sh.mintok >= 4u) piece_exit_lds<true, false>(sh, (uint32_t)tid, wlead, nw);
+                if (min4) piece_exit_lds<true, false>(sh, (uint32_t)tid, wlead, nw);
                 else piece_exit_lds<false, false>(sh, (uint32_t)tid, wlead, nw);
             }
             PHASE(2);
@@ -1357,12 +1364,12 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         PHASE(3);
         /* P3: walk from the true entry, counting */
         SubResult r;
-        const bool dbl = sh.dbl != 0u; /* (block-uniform) */
+        const bool dbl = uni(sh.dbl) != 0u; /* (block-uniform) */
 #ifndef MRCZ_STAGED
 #define MRCZ_STAGED 1
 #endif
         /* blocks of long codes keep the bytes their count walk decodes (stage_walk) */
-        const bool staged = MRCZ_STAGED && !dbl && sub <= 37u * sh.mintok; /* (block- and window-uniform) */
+        const bool staged = MRCZ_STAGED && !dbl && sub <= 37u * uni(sh.mintok); /* (block- and window-uniform) */
         if ((EXP_DOUBLE & 2) && start != POS_INVALID) { /* what-if timing builds only: one more count walk */
             const SubResult x = dbl ? count_walk<true, false, true>(sh, start, limit) : count_walk<true>(sh, start, limit);
             asm volatile("" :: "v"(x.nout), "v"(x.land), "v"(x.lastlit), "v"(x.flags));
@@ -1376,13 +1383,14 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
         else { r.land = POS_INVALID; r.nout = 0; r.flags = 0; r.lastlit = 0; }
         PHASE(4);
         const bool active = start != POS_INVALID;
-        const uint32_t haslit0 = sh.haslit; /* (thread PT-1 rewrites them at the end of the window) */
-        const uint32_t lastin = sh.last;
-        const uint32_t op = sh.op;
+        const uint32_t haslit0 = uni(sh.haslit); /* (thread PT-1 rewrites them at the end of the window) */
+        const uint32_t lastin = uni(sh.last);
+        const uint32_t op = uni(sh.op);
         const WinScan ws = window_scan(sh, tid, active ? r.nout : 0u, active ? r.lastlit : 0u, r.flags);
-        const uint32_t e = ws.stop_tid; /* first lane that ended the block (or failed); lanes after it are inactive */
-        const uint32_t total = ws.total, myoff = ws.myoff, before = ws.before;
-        const uint32_t bad_flags = ws.bad ? (ws.bad | (uint32_t)F_ERR) : 0u;
+        const uint32_t e = uni(ws.stop_tid); /* first lane that ended the block (or failed); lanes after it are inactive */
+        const uint32_t total = uni(ws.total), myoff = ws.myoff, before = ws.before;
+        const uint32_t wsbad = uni(ws.bad);
+        const uint32_t bad_flags = wsbad ? (wsbad | (uint32_t)F_ERR) : 0u;
         PHASE(5);
         if (bad_flags || op + total > sv.n) {
             if (tid == 0) sh.status = (bad_flags & F_GENERAL) ? 3 : 2;
@@ -1418,12 +1426,13 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
                 sh.nwin = widx;
             }
             __syncthreads(); /* sh.wbase */
-            if (sh.wbase == 0xffffffffu) { /* more windows than a candidate records, or the scratch buffer is full */
+            const uint32_t wbase = uni(sh.wbase);
+            if (wbase == 0xffffffffu) { /* more windows than a candidate records, or the scratch buffer is full */
                 if (tid == 0) sh.status = 2;
                 __syncthreads();
                 break;
             }
-            wout = (sh.wbase >= WB_CONST_LEAD) ? nullptr : so.base + (size_t)sh.wbase * 16u + myoff;
+            wout = (wbase >= WB_CONST_LEAD) ? nullptr : so.base + (size_t)wbase * 16u + myoff;
             if (!haslit0) {
                 /* the bytes in front of the block's first literal replicate the previous block's last byte, which is
                  * not known here: remember how many there are, the merge fills them in */
@@ -2089,7 +2098,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     for (;;) {
         if (tid == 0) sh.flag = atomicAdd(jobctr, 1u);
         __syncthreads();
-        const uint32_t job = sh.flag;
+        const uint32_t job = uni(sh.flag);
         __syncthreads(); /* everybody has read the job number before sh.flag is reused */
         if (job >= total) break; /* uniform: every wave leaves in the same iteration */
         uint32_t lo = 0, hi = nstreams - 1;
@@ -2112,13 +2121,13 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 const uint32_t b = cands[(size_t)s * MAXCAND + j].bit;
                 if (b > mybit && b < m) m = b;
             }
-            hint = block_min_pt(m, sh.scan_a); /* (its barriers also publish the lines above) */
+            hint = uni(block_min_pt<false>(m, sh.scan_a)); /* (its barrier also publishes the lines above; scan_a is next written behind the block's first barriers) */
             if (!use_hint) hint = 0xffffffffu;
         }
         ScratchOut so;
         so.base = scratch; so.top = scratch_top; so.cap16 = scratch_cap16; so.wbase = c->wbase; so.wlen = c->wlen;
         decode_one_block<MODE_SCRATCH>(sh, sv, tid, dbg, so, hdrs + ((size_t)s * MAXCAND + ci), hdr_tag(calltag, c->bit), hint);
-        __syncthreads();
+        /* (no barrier: every way out of decode_one_block lies behind one that follows its last writes) */
         if (tid == 0) {
             const bool ok = (sh.status == 0 || sh.status == 1) && sh.cur > c->bit;
             c->end = sh.cur;
