@@ -403,7 +403,7 @@ __device__ __forceinline__ uint32_t tok_entry(const ParShared &sh, uint32_t sym,
  * pattern, each pattern searching its code length among the limits and then recomputed once more for the token fields:
  * a fifth of the kernel's vector instructions.  `mycode` = huff_core's canonical code of the thread's symbol.  sh.complete says
  * whether every pattern got its token bits. */
-__device__ __forceinline__ void tok_table_build(ParShared &sh, int tid, uint32_t mycode)
+__device__ __noinline__ void tok_table_build(ParShared &sh, int tid, uint32_t mycode)
 {
     constexpr int EPT = (1 << LBITS) / PT;
 #pragma unroll
@@ -429,7 +429,35 @@ __device__ __forceinline__ void tok_table_build(ParShared &sh, int tid, uint32_t
             sh.tok[idx] = e;
         }
     }
-    const uint32_t nshort = sh.lit.offs[7]; /* symbols with codes of 1..6 bits: the first ones of the sorted list */
+#ifndef MRCZ_TOK_BY_PATTERN
+#define MRCZ_TOK_BY_PATTERN 1
+#endif
+    uint32_t nshort = uni(sh.lit.offs[7]); /* symbols with codes of 1..6 bits: the first ones of the sorted list */
+    if (MRCZ_TOK_BY_PATTERN && uni(sh.lit.offs[4]) != 0u) {
+        /* A block with codes of 1..3 bits (an exponent plane) has a dozen symbols of 1..6 bits that own nearly the whole table.
+         * Symbol after symbol, the workgroup passed a chain of dependent LDS reads per symbol (its place in the sorted list,
+         * its length, the first code of that length, then the entries' own distance look-ups): 52 k clocks per block, 15 % of
+         * such a block's time.  Here every thread sizes its own eight patterns against the six limits (scalar registers) and
+         * looks their symbols up: eight independent chains per thread. */
+        uint32_t lim[7], fst[7], ofs[7];
+#pragma unroll
+        for (int k = 1; k <= 6; k++) { lim[k] = uni(sh.lit.limit[k]); fst[k] = uni(sh.lit.first[k]); ofs[k] = uni(sh.lit.offs[k]); }
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const uint32_t idx = (uint32_t)tid + (uint32_t)(k * PT);
+            const uint32_t x = (__brev(idx) >> (32 - LBITS)) << (15 - LBITS); /* left-justified 15-bit prefix */
+            uint32_t len = 0, f = 0, o = 0;
+#pragma unroll
+            for (int kk = 6; kk >= 1; kk--) if (x < lim[kk]) { len = (uint32_t)kk; f = fst[kk]; o = ofs[kk]; } /* smallest length whose codes reach x */
+            if (len) {
+                const uint32_t sym = sh.lit.sorted[o + ((x >> (15u - len)) - f)];
+                const uint32_t e = tok_entry(sh, sym, len, idx);
+                zero |= (e & 0xffu) == 0u;
+                sh.tok[idx] = e;
+            }
+        }
+        nshort = 0;
+    }
     for (uint32_t i = 0; i < nshort; i++) { /* (workgroup-uniform) */
         const uint32_t sym = sh.lit.sorted[i], l = sh.lens[sym] & 7u;
         if (l == 0u) continue; /* (never: the sorted list holds coded symbols) */
