@@ -249,7 +249,7 @@ __device__ __forceinline__ void huff_tables_wave(H &h, int lane, int nwaves)
  * wave 5) of a block TOGETHER: three barriers instead of the eight of two huff_core calls -- a block's tables are a chain of
  * short phases, and what they cost is their barriers.  Returns the canonical code of the thread's literal/length symbol. */
 struct ParShared;
-__device__ __forceinline__ uint32_t huff_core_litdist(ParShared &sh, int tid);
+__device__ __noinline__ uint32_t huff_core_litdist(ParShared &sh, int tid);
 /* decode one symbol from the low bits of v (>= 15 valid bits); returns sym | len << 16, or 0xffffffff.
  * Codes longer than the table's index bits are resolved by comparing the left-justified 15-bit
  * prefix against the per-length limits (canonical codes are ordered by length), not by a bit loop. */
@@ -320,7 +320,7 @@ __device__ __noinline__ uint32_t token_bits(const ParShared &sh, unsigned long l
     return t > (uint32_t)MAXTOK ? X_ERR : t;
 }
 
-__device__ __forceinline__ uint32_t huff_core_litdist(ParShared &sh, int tid)
+__device__ __noinline__ uint32_t huff_core_litdist(ParShared &sh, int tid)
 {
     static_assert(PT >= 384 && HuffAux::NW == 5, "waves 0..4 own the literal/length symbols, wave 5 the distance symbols");
     const int w = tid >> 6, l = tid & 63;
