@@ -692,6 +692,17 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
     return r;
 }
 
+/* the walks one lane of a window makes once in a while (is the window one repeated byte? where is the block's first literal?),
+ * out of line: four more instances of the walk inside the kernel's main function cost it registers */
+__device__ __noinline__ uint32_t count_literals(const ParShared &sh, uint32_t start, uint32_t limit, bool dbl)
+{
+    return dbl ? count_walk<false, false, true, true>(sh, start, limit).nout : count_walk<false, false, false, true>(sh, start, limit).nout;
+}
+__device__ __noinline__ uint32_t bytes_before_first_literal(const ParShared &sh, uint32_t start, uint32_t limit, bool dbl)
+{
+    return dbl ? count_walk<false, true, true>(sh, start, limit).nout : count_walk<false, true>(sh, start, limit).nout;
+}
+
 /* P3 for blocks of long codes (a mantissa plane: every token a literal of 7..9 bits, a match once in a few thousand): the count
  * walk KEEPS what it decodes.  A piece of 256 bits holds at most 37 such tokens; their bytes go, four at a time, into the lane's
  * column of ParShared::ring (dead once the entries are known: 32 bytes per lane) and the ninth dword stays in a register.  The
@@ -1016,7 +1027,7 @@ __device__ __forceinline__ uint32_t hdr_token(const ParShared &sh, uint32_t v)
 constexpr int HB2 = 16;   /* header bits per thread */
 constexpr int HNP = 288;  /* pieces: 4608 bits >= any dynamic header */
 
-__device__ __forceinline__ void hdr_lengths_block(ParShared &sh, int tid, uint32_t cur, uint32_t lead)
+__device__ __noinline__ void hdr_lengths_block(ParShared &sh, int tid, uint32_t cur, uint32_t lead) /* (out of line: rare, and its registers are not the walks') */
 {
     const int lane = tid & 63, wv = tid >> 6;
     const uint32_t hbase = sh.hpos + 3u * sh.ncode;
@@ -1166,6 +1177,41 @@ __device__ __forceinline__ StreamView make_view(const uint8_t *rec, uint64_t rec
         }                                                                \
     } while (0)
 
+/* the pair pass of a block's tables (all PT threads; out of line like the other table phases) */
+__device__ __noinline__ void tok_pair_pass(ParShared &sh, int tid)
+{
+        /* Two literals per step: in blocks of short codes a literal's entry also carries the literal behind it when both codes fit
+         * in the index bits (no literal of 6 bits or less, no pairs: a mantissa plane skips the pass). */
+        constexpr int EPT = (1 << LBITS) / PT;
+        bool pairs = false;
+        if (sh.lit.offs[7] != 0u) { /* (workgroup-uniform) */
+            uint32_t second[EPT];
+            uint32_t ndbl = 0;
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)(k * PT);
+                const uint32_t e = sh.tok[i], t = e & 0xffu;
+                second[k] = 0;
+                if ((int32_t)e >= 0 && ((e >> TOK_N_SHIFT) & 0x1ffu) == 1u && t < (uint32_t)LBITS) { /* a literal: is the token behind it a literal inside the index bits too? */
+                    const uint32_t e2 = sh.tok[i >> t];
+                    const uint32_t l2 = (e2 >> TOK_LEN_SHIFT) & 15u, sym2 = (e2 >> TOK_SYM_SHIFT) & 511u;
+                    if (l2 != 0u && t + l2 <= (uint32_t)LBITS && sym2 < 256u) { second[k] = TOK_PAIR | (l2 << TOK_LEN_SHIFT) | (sym2 << TOK_B2_SHIFT); ndbl++; }
+                }
+            }
+            if (ndbl) atomicAdd(&sh.ndbl, ndbl);
+            __syncthreads();
+            /* worth the walks' extra test when a quarter of the patterns are pairs; otherwise the table stays as the plain walks read it */
+            pairs = sh.ndbl >= (1u << LBITS) / 4u;
+            if (pairs) {
+#pragma unroll
+                for (int k = 0; k < EPT; k++)
+                    if (second[k]) sh.tok[tid + k * PT] = (sh.tok[tid + k * PT] & ~(15u << TOK_LEN_SHIFT)) | second[k];
+            }
+            /* (no barrier: the table is next read behind the first window's staging barrier, and the count has its own word) */
+        }
+        if (tid == 0) sh.dbl = pairs ? 1u : 0u;
+    }
+
 /* Decode ONE deflate block of a stream: it starts at payload bit sh.cur, its plane bytes go to
  * sv.out + sh.op (WRITE) or are only counted (!WRITE).  On return sh.cur is the first bit after the
  * block, sh.op has advanced by the bytes produced, sh.last/sh.haslit hold the last byte produced, and
@@ -1275,38 +1321,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
     PHASE(16);
     if (EXP_DOUBLE & 4) tok_table_build(sh, tid, mycode); /* what-if timing builds only */
     tok_table_build(sh, tid, mycode);
-    {
-        /* Two literals per step: in blocks of short codes a literal's entry also carries the literal behind it when both codes fit
-         * in the index bits (no literal of 6 bits or less, no pairs: a mantissa plane skips the pass). */
-        constexpr int EPT = (1 << LBITS) / PT;
-        bool pairs = false;
-        if (sh.lit.offs[7] != 0u) { /* (workgroup-uniform) */
-            uint32_t second[EPT];
-            uint32_t ndbl = 0;
-#pragma unroll
-            for (int k = 0; k < EPT; k++) {
-                const uint32_t i = (uint32_t)tid + (uint32_t)(k * PT);
-                const uint32_t e = sh.tok[i], t = e & 0xffu;
-                second[k] = 0;
-                if ((int32_t)e >= 0 && ((e >> TOK_N_SHIFT) & 0x1ffu) == 1u && t < (uint32_t)LBITS) { /* a literal: is the token behind it a literal inside the index bits too? */
-                    const uint32_t e2 = sh.tok[i >> t];
-                    const uint32_t l2 = (e2 >> TOK_LEN_SHIFT) & 15u, sym2 = (e2 >> TOK_SYM_SHIFT) & 511u;
-                    if (l2 != 0u && t + l2 <= (uint32_t)LBITS && sym2 < 256u) { second[k] = TOK_PAIR | (l2 << TOK_LEN_SHIFT) | (sym2 << TOK_B2_SHIFT); ndbl++; }
-                }
-            }
-            if (ndbl) atomicAdd(&sh.ndbl, ndbl);
-            __syncthreads();
-            /* worth the walks' extra test when a quarter of the patterns are pairs; otherwise the table stays as the plain walks read it */
-            pairs = sh.ndbl >= (1u << LBITS) / 4u;
-            if (pairs) {
-#pragma unroll
-                for (int k = 0; k < EPT; k++)
-                    if (second[k]) sh.tok[tid + k * PT] = (sh.tok[tid + k * PT] & ~(15u << TOK_LEN_SHIFT)) | second[k];
-            }
-            /* (no barrier: the table is next read behind the first window's staging barrier, and the count has its own word) */
-        }
-        if (tid == 0) sh.dbl = pairs ? 1u : 0u;
-    }
+    tok_pair_pass(sh, tid);
     /* (sh.mintok comes out of tok_table_build; the first window's staging barrier publishes what thread 0 wrote above) */
     PHASE(0);
     /* ---------------- block body, window by window ---------------- */
@@ -1437,9 +1452,9 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
                 uint32_t wconst = 0; /* 0 = ordinary window, else WB_CONST | byte, or WB_CONST_LEAD (bytes before the block's first literal) */
                 if (!ws.lit_after0 && total != 0u) {
                     uint32_t nl = 0;
-                    if (r.lastlit) nl = dbl ? count_walk<false, false, true, true>(sh, start, limit).nout : count_walk<false, false, false, true>(sh, start, limit).nout;
+                    if (r.lastlit) nl = count_literals(sh, start, limit, dbl);
                     if (nl == 0u) wconst = haslit0 ? (WB_CONST | (lastin & 0xffu)) : WB_CONST_LEAD;
-                    else if (nl == 1u && (dbl ? count_walk<false, true, true>(sh, start, limit).nout : count_walk<false, true>(sh, start, limit).nout) == 0u)
+                    else if (nl == 1u && bytes_before_first_literal(sh, start, limit, dbl) == 0u)
                         wconst = WB_CONST | (r.lastlit & 0xffu);
                 }
                 const uint32_t units = wconst ? 0u : (total + 15u) >> 4;
@@ -1464,7 +1479,7 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
             if (!haslit0) {
                 /* the bytes in front of the block's first literal replicate the previous block's last byte, which is
                  * not known here: remember how many there are, the merge fills them in */
-                if ((uint32_t)tid == ws.firstlit_tid) sh.lead = op + myoff + (dbl ? count_walk<false, true, true>(sh, start, limit).nout : count_walk<false, true>(sh, start, limit).nout);
+                if ((uint32_t)tid == ws.firstlit_tid) sh.lead = op + myoff + bytes_before_first_literal(sh, start, limit, dbl);
             }
         } else wout = sv.out + op + myoff;
 #ifndef EXP_SKIP_P4
