@@ -721,22 +721,25 @@ __device__ __forceinline__ SubResult stage_walk(ParShared &sh, uint32_t start, u
     while (pos < limit) {
         WALK_BITS_REFILL(pos);
         const uint32_t e = WALK_TOK();
-        if ((int32_t)e >= 0) {
-            const uint32_t t = e & 0xffu, n = (e >> TOK_N_SHIFT) & 0x1ffu;
+        /* a literal the table resolves and room to keep it -- nearly every step: one test, one path (its byte is counted behind
+         * the loop, with the staged ones) */
+        if ((e & (TOK_SLOW | (0x1ffu << TOK_N_SHIFT))) == (1u << TOK_N_SHIFT) && cnt < STG_CAP) {
+            const uint32_t t = e & 0xffu;
             buf >>= t; nb -= (int)t; pos += t;
-            r.nout += n;
-            if (n == 1u && cnt < STG_CAP) {
-                laste = e;
-                accw = __byte_perm(accw, e, 0x5321); /* accw >> 8 | literal << 24: the literal is byte 1 of its entry */
-                cnt++;
-                if ((cnt & 3u) == 0u && cnt <= 32u) sh.ring[(cnt >> 2) - 1u][tid] = accw;
-            } else {
-                if (n == 1u) laste = e;
-                slow = STG_SLOW;
-            }
+            laste = e;
+            accw = __byte_perm(accw, e, 0x5321); /* accw >> 8 | literal << 24: the literal is byte 1 of its entry */
+            cnt++;
+            if ((cnt & 3u) == 0u && cnt <= 32u) sh.ring[(cnt >> 2) - 1u][tid] = accw;
             continue;
         }
         slow = STG_SLOW;
+        if ((int32_t)e >= 0) { /* a match, or a literal beyond the staging room */
+            const uint32_t t = e & 0xffu, n = (e >> TOK_N_SHIFT) & 0x1ffu;
+            buf >>= t; nb -= (int)t; pos += t;
+            r.nout += n;
+            if (n == 1u) laste = e;
+            continue;
+        }
         const uint32_t g = count_general_token(sh, pos);
         r.flags |= (g >> CG_FLAG_SHIFT) & 7u;
         pos += g & 0xffu;
@@ -746,6 +749,7 @@ __device__ __forceinline__ SubResult stage_walk(ParShared &sh, uint32_t start, u
         WALK_BITS_RESYNC(pos);
     }
     if (laste) r.lastlit = 0x100u | ((laste >> TOK_SYM_SHIFT) & 0xffu);
+    r.nout += cnt;
     r.land = pos;
     sg.cnt = cnt | slow;
     sg.w9 = accw;
