@@ -66,6 +66,25 @@ def test_one_gib_container_equals_the_oracle(oracle):
     big.close()
 
 
+def test_one_gib_twelve_bits_equals_the_oracle(oracle):
+    """The same volume at b = 12 (BASELINE's mask sweep): plane 1 becomes a plane of 4-bit codes, every block of which is one full
+    16 KiB window and a stub of ~500 bytes -- the case the merge's three-segments-per-tile path and the hint-sized windows exist for."""
+    import torch
+    from datacompressionfloat_amd import MrcZipCodec
+    n = 268435456
+    w = util.gauss_words(n, seed=1234)
+    ref = oracle.compress(w, 12, threads=CORES)
+    big = MrcZipCodec(0, max_batch_chunks=43)
+    dev = torch.from_numpy(w.view(np.int32)).cuda()
+    rec, planes = big.compress_device(dev, 12, 0)
+    assert rec.numel() == len(ref) - 17 and sum(planes) == rec.numel()
+    assert np.array_equal(rec.cpu().numpy(), np.frombuffer(ref, np.uint8)[17:]), "the 1 GiB container (b = 12) differs from the oracle's"
+    out, consumed = big.uncompress_device(rec, n)
+    assert consumed == rec.numel() and big.last_fallbacks() == 0
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), util.erase_expected(w, 12))
+    big.close()
+
+
 def test_sixty_four_gib_streamed_through_one_gpu(oracle):
     """BASELINE config 4 (bnr_large.sh shape) on ONE GPU: 2731 chunks in 22 batches of 128, what bench.py --gib-per-gpu 64 does."""
     import torch
