@@ -870,7 +870,7 @@ __device__ __forceinline__ void packer_finish(LanePacker &p)
 }
 
 #ifndef EMIT_WAVES
-#define EMIT_WAVES 4 /* 123 VGPRs, no spills; with 9.1 KB of LDS per wave 16-17 waves fit a CU (measured: 5 is slower, it spills) */
+#define EMIT_WAVES 5 /* waves per SIMD: 94 VGPRs, no spills, 6.1 KB of LDS per wave (4: 104 VGPRs, kernel 1.00 ms instead of 0.90; 6: 80 VGPRs, ten of them spilled, 0.93) */
 #endif
 #define OPAQUE4(x, q) asm volatile("" : "+v"((x)[4 * (q)]), "+v"((x)[4 * (q) + 1]), "+v"((x)[4 * (q) + 2]), "+v"((x)[4 * (q) + 3]))
 
