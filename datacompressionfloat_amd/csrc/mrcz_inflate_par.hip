@@ -1367,43 +1367,89 @@ __device__ __forceinline__ void decode_one_block(ParShared &sh, const StreamView
              * broadcast LDS read), which yields the half's and then the wave's exit function.  After the waves'
              * functions are chained (one barrier), pass 2 reads the chain from the now known entry off the lane that followed
              * exactly that entry in pass 1. */
-            const int l = lane_id(), k = l & 31;
-            const uint8_t *hf = reinterpret_cast<const uint8_t *>(&sh.ring[0][(tid & ~63) | (l & 32)]); /* first piece of my half */
-            __builtin_amdgcn_wave_barrier();
-            /* Pass 1 keeps what it sees: traj byte i = where the chain that enters the half at offset k stands in front of piece i
-             * (5-bit values, four to a register; the loop is unrolled so that every byte position is a constant).  Pass 2 then
-             * needs no second walk: the chain from the half's true entry e is lane e's trajectory, fetched with eight
-             * independent cross-lane reads instead of 32 dependent LDS reads. */
-            uint32_t traj[8];
-            uint32_t v = k < MAXTOK ? (uint32_t)k : (uint32_t)X_ERR;
+#ifndef MRCZ_P2_NARROW
+#define MRCZ_P2_NARROW 1
+#endif
+            if (MRCZ_P2_NARROW && uni(sh.nlen) <= 257u) {
+                /* A block without length codes (HLIT = 257: literals and END_BLOCK only -- nearly every block of a mantissa plane):
+                 * a token is one code of at most 15 bits, so a piece is entered at an offset below 16 and FOUR chains of 16
+                 * pieces fit the wave's 64 lanes (lane = quarter * 16 + entry offset) where the general form below runs two
+                 * chains of 32: half the dependent LDS round trips, which is what this phase consists of. */
+                const int l = lane_id(), q = l >> 4, k = l & 15;
+                const uint8_t *qf = reinterpret_cast<const uint8_t *>(&sh.ring[0][(tid & ~63) | (l & 48)]); /* first piece of my quarter */
+                __builtin_amdgcn_wave_barrier();
+                uint32_t traj[4];
+                uint32_t v = (uint32_t)k;
 #pragma unroll
-            for (int i = 0; i < 32; i++) {
-                if ((i & 3) == 0) traj[i >> 2] = v; else traj[i >> 2] |= v << (8 * (i & 3));
-                if (v < (uint32_t)MAXTOK) v = hf[ring_off(v) + 4u * (uint32_t)i];
-            }
-            {
-                /* wave function = second half after first half */
-                const uint32_t second = (uint32_t)__shfl((int)v, 32 + (int)(v < (uint32_t)MAXTOK ? v : 0u));
-                const uint32_t tot = v < (uint32_t)MAXTOK ? second : v;
-                if (l < MAXTOK) sh.wtot[tid >> 6][l] = (uint8_t)tot;
-            }
-            __syncthreads();
-            uint32_t e = 0; /* the window is staged so that its first piece starts on a token */
-            for (int ww = 0; ww < (tid >> 6) && e < (uint32_t)MAXTOK; ww++) e = sh.wtot[ww][e];
-            {
-                /* entry of the second half = first half's function at the wave entry */
-                const uint32_t h1 = (uint32_t)__shfl((int)v, (int)(e < (uint32_t)MAXTOK ? e : 0u));
-                if ((l & 32) && e < (uint32_t)MAXTOK) e = h1;
-            }
-            {
-                const int src = (l & 32) + (int)(e < (uint32_t)MAXTOK ? e : 0u); /* the lane that followed my half's entry */
-                uint32_t word = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t t = (uint32_t)__shfl((int)traj[j], src);
-                    word = (k >> 2) == j ? t : word;
+                for (int i = 0; i < 16; i++) {
+                    if ((i & 3) == 0) traj[i >> 2] = v; else traj[i >> 2] |= v << (8 * (i & 3));
+                    if (v < (uint32_t)MAXTOK) v = qf[ring_off(v) + 4u * (uint32_t)i];
                 }
-                entry = e < (uint32_t)MAXTOK ? (word >> (8 * (k & 3))) & 0xffu : e;
+                /* v = my quarter's function at k.  The wave's function at k: through the four quarters with lane reads */
+                auto through = [&](uint32_t x, int quarter) -> uint32_t { /* (every lane takes part in the read) */
+                    const uint32_t r = (uint32_t)__shfl((int)v, 16 * quarter + (int)(x < (uint32_t)MAXTOK ? x : 0u));
+                    return x < (uint32_t)MAXTOK ? r : x;
+                };
+                {
+                    const uint32_t tot = through(through(through(through((uint32_t)k, 0), 1), 2), 3);
+                    if (l < MAXTOK) sh.wtot[tid >> 6][l] = (uint8_t)(l < 16 ? tot : (uint32_t)X_ERR);
+                }
+                __syncthreads();
+                uint32_t e = 0; /* the window is staged so that its first piece starts on a token */
+                for (int ww = 0; ww < (tid >> 6) && e < (uint32_t)MAXTOK; ww++) e = sh.wtot[ww][e];
+                /* entries of the quarters */
+                const uint32_t e1 = through(e, 0), e2 = through(e1, 1), e3 = through(e2, 2);
+                const uint32_t eq = q == 0 ? e : q == 1 ? e1 : q == 2 ? e2 : e3;
+                {
+                    const int src = 16 * q + (int)(eq < (uint32_t)MAXTOK ? eq : 0u); /* the lane that followed my quarter's entry */
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t t = (uint32_t)__shfl((int)traj[j], src);
+                        word = (k >> 2) == j ? t : word;
+                    }
+                    entry = eq < (uint32_t)MAXTOK ? (word >> (8 * (k & 3))) & 0xffu : eq;
+                }
+            } else {
+                const int l = lane_id(), k = l & 31;
+                const uint8_t *hf = reinterpret_cast<const uint8_t *>(&sh.ring[0][(tid & ~63) | (l & 32)]); /* first piece of my half */
+                __builtin_amdgcn_wave_barrier();
+                /* Pass 1 keeps what it sees: traj byte i = where the chain that enters the half at offset k stands in front of piece i
+                 * (5-bit values, four to a register; the loop is unrolled so that every byte position is a constant).  Pass 2 then
+                 * needs no second walk: the chain from the half's true entry e is lane e's trajectory, fetched with eight
+                 * independent cross-lane reads instead of 32 dependent LDS reads. */
+                uint32_t traj[8];
+                uint32_t v = k < MAXTOK ? (uint32_t)k : (uint32_t)X_ERR;
+    #pragma unroll
+                for (int i = 0; i < 32; i++) {
+                    if ((i & 3) == 0) traj[i >> 2] = v; else traj[i >> 2] |= v << (8 * (i & 3));
+                    if (v < (uint32_t)MAXTOK) v = hf[ring_off(v) + 4u * (uint32_t)i];
+                }
+                {
+                    /* wave function = second half after first half */
+                    const uint32_t second = (uint32_t)__shfl((int)v, 32 + (int)(v < (uint32_t)MAXTOK ? v : 0u));
+                    const uint32_t tot = v < (uint32_t)MAXTOK ? second : v;
+                    if (l < MAXTOK) sh.wtot[tid >> 6][l] = (uint8_t)tot;
+                }
+                __syncthreads();
+                uint32_t e = 0; /* the window is staged so that its first piece starts on a token */
+                for (int ww = 0; ww < (tid >> 6) && e < (uint32_t)MAXTOK; ww++) e = sh.wtot[ww][e];
+                {
+                    /* entry of the second half = first half's function at the wave entry */
+                    const uint32_t h1 = (uint32_t)__shfl((int)v, (int)(e < (uint32_t)MAXTOK ? e : 0u));
+                    if ((l & 32) && e < (uint32_t)MAXTOK) e = h1;
+                }
+                {
+                    const int src = (l & 32) + (int)(e < (uint32_t)MAXTOK ? e : 0u); /* the lane that followed my half's entry */
+                    uint32_t word = 0;
+    #pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t t = (uint32_t)__shfl((int)traj[j], src);
+                        word = (k >> 2) == j ? t : word;
+                    }
+                    entry = e < (uint32_t)MAXTOK ? (word >> (8 * (k & 3))) & 0xffu : e;
+                }
+        
             }
         }
         widx++;
