@@ -631,21 +631,27 @@ __device__ __noinline__ uint32_t count_general_token(const ParShared &sh, uint32
     return (l + xb + dl + dxb) | (ml << 8) | (dist != 1u ? (uint32_t)F_GENERAL << CG_FLAG_SHIFT : 0u);
 }
 
-/* the walks' bit buffer: 64 bits of the window from bit `pos` on */
+/* The walks' bit buffer.  `buf` holds the window's bits from bit `pos` on, SHIFTED LEFT BY TWO: the byte offset of the token
+ * table's entry is one AND of its low word (bits 0..1 are junk the mask drops).  Only the position is counted, not the bits
+ * left: the buffer is filled up to window bit thr + 30, and a step that moves the position beyond `thr` leaves fewer than 30
+ * bits (a token is at most MAXTOK = 24) and takes the next dword.  Two vector instructions per token less than a buffer with a
+ * bit count, in loops of a dozen and a half. */
 #define WALK_BITS_INIT(pos_)                                                                                          \
     uint32_t wi = (pos_) >> 5;                                                                                        \
-    uint64_t buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> ((pos_) & 31u);            \
-    int nb = 64 - (int)((pos_) & 31u);                                                                                \
-    wi += 2
+    uint64_t buf = (uint64_t)(sh.win[WSK(wi)] >> ((pos_) & 31u)) << 2;                                                \
+    uint32_t thr = (wi << 5) + 2u;                                                                                    \
+    wi += 1
 #define WALK_BITS_RESYNC(pos_)                                                                                        \
     do {                                                                                                              \
         wi = (pos_) >> 5;                                                                                             \
-        buf = ((uint64_t)sh.win[WSK(wi)] | ((uint64_t)sh.win[WSK(wi + 1)] << 32)) >> ((pos_) & 31u);                 \
-        nb = 64 - (int)((pos_) & 31u);                                                                                \
-        wi += 2;                                                                                                      \
+        buf = (uint64_t)(sh.win[WSK(wi)] >> ((pos_) & 31u)) << 2;                                                     \
+        thr = (wi << 5) + 2u;                                                                                         \
+        wi += 1;                                                                                                      \
     } while (0)
-#define WALK_BITS_REFILL(pos_) if (nb < 32) { buf |= (uint64_t)sh.win[WSK(wi)] << nb; wi++; nb += 32; }
-#define WALK_TOK() sh.tok[(uint32_t)buf & ((1u << LBITS) - 1u)]
+#define WALK_BITS_REFILL(pos_)                                                                                        \
+    if ((pos_) > thr) { buf |= (uint64_t)sh.win[WSK(wi)] << (thr + 32u - (pos_)); wi++; thr += 32u; }
+/* the token table's entry for the next LBITS bits of the buffer */
+#define WALK_TOK() (*reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(sh.tok) + ((uint32_t)buf & (((1u << LBITS) - 1u) << 2))))
 
 /* P3: count walk.  Decode tokens from window bit `start` until the position reaches `limit` (or
  * END_BLOCK), counting the plane bytes they produce.  Nearly every token is sized by ONE 12-bit lookup. */
@@ -666,14 +672,14 @@ __device__ __forceinline__ SubResult count_walk(const ParShared &sh, uint32_t st
                 if (STOP_AT_LIT) break;
                 const bool both = pos + t < limit; /* the second literal starts inside this piece: both in one step */
                 const uint32_t tt = t + (both ? (e >> TOK_LEN_SHIFT) & 15u : 0u);
-                buf >>= tt; nb -= (int)tt; pos += tt;
+                buf >>= tt; pos += tt;
                 r.nout += both ? 2u : 1u;
                 if (TRACK_LAST) { r.lastlit = 0x100u | (both ? (e >> TOK_B2_SHIFT) & 0xffu : (e >> TOK_SYM_SHIFT) & 0xffu); laste = 0; }
                 continue;
             }
             const uint32_t n = (e >> TOK_N_SHIFT) & 0x1ffu;
             if (STOP_AT_LIT && n == 1u) break;
-            buf >>= t; nb -= (int)t; pos += t;
+            buf >>= t; pos += t;
             r.nout += NLIT ? (n == 1u ? 1u : 0u) : n;
             if (TRACK_LAST) laste = n == 1u ? e : laste;
             continue;
@@ -725,7 +731,7 @@ __device__ __forceinline__ SubResult stage_walk(ParShared &sh, uint32_t start, u
          * the loop, with the staged ones) */
         if ((e & (TOK_SLOW | (0x1ffu << TOK_N_SHIFT))) == (1u << TOK_N_SHIFT) && cnt < STG_CAP) {
             const uint32_t t = e & 0xffu;
-            buf >>= t; nb -= (int)t; pos += t;
+            buf >>= t; pos += t;
             laste = e;
             accw = __byte_perm(accw, e, 0x5321); /* accw >> 8 | literal << 24: the literal is byte 1 of its entry */
             cnt++;
@@ -735,7 +741,7 @@ __device__ __forceinline__ SubResult stage_walk(ParShared &sh, uint32_t start, u
         slow = STG_SLOW;
         if ((int32_t)e >= 0) { /* a match, or a literal beyond the staging room */
             const uint32_t t = e & 0xffu, n = (e >> TOK_N_SHIFT) & 0x1ffu;
-            buf >>= t; nb -= (int)t; pos += t;
+            buf >>= t; pos += t;
             r.nout += n;
             if (n == 1u) laste = e;
             continue;
@@ -857,7 +863,7 @@ __device__ __forceinline__ void write_walk(const ParShared &sh, uint32_t start, 
                     last = n == 1u ? (e >> TOK_SYM_SHIFT) & 0xffu : last;
                     pat = last * 0x01010101u;
                 }
-                buf >>= t; nb -= (int)t; pos += t;
+                buf >>= t; pos += t;
             } else {
                 const uint32_t g = walk_general_token(sh, pos);
                 if (g == 0u) break;
